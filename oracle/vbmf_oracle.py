@@ -1,0 +1,471 @@
+"""CPU oracle: fp64 NumPy restatement of the reference's VB matrix-factorization path.
+
+THIS IS TEST INFRASTRUCTURE, NOT PRODUCT.  Only tests/, __graft_entry__.smoke() and bench.py's
+`cpu_baseline` leg may import it; the product path (vbmatrixfactorization.jl_amd) never does and
+fails loudly when the HIP library is missing.
+
+Parity status: PINNED for the basic path (updateA!/updateB!/updateCA!/updateCB!/updateSigma2! and the
+est_covs=est_var=true driver) and for the sparse full_cov=true path by the reference's own recorded
+trajectories (tests/golden/*.npz, extracted from examples/data/{vbmf_test,sparse_test}/*.jld);
+see tests/test_oracle_golden.py.  UNPINNED (no reference number exists anywhere): the convergence
+scalar d, label/H1 masking, est_covs/est_var=false, the sparse diagonal branch, lowerBound, and the
+basic-model ELBO (the reference defines none).
+
+The reference is Julia 0.5 source (cannot run in this pipeline: no julia binary).  Every function
+cites the reference lines it follows; paths are relative to /root/reference.
+
+Conventions: arrays are NumPy float64, Y is (L, M), AHat (M, H), BHat (L, H).  `labels` are 0-based
+row indices of AHat here (the reference's are 1-based Julia indices).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field, fields
+from typing import Optional
+
+import numpy as np
+
+LN2PI = math.log(2.0 * math.pi)            # src/util.jl:1
+EPS0 = 4.9406564584124654e-324             # Julia eps(0.0), src/util.jl:120-122
+
+
+# ----------------------------------------------------------------------------------------------
+# numeric helpers  (src/util.jl)
+# ----------------------------------------------------------------------------------------------
+def norm2(x):
+    """src/util.jl:8-19 -- sum(x.^2)."""
+    return float(np.sum(np.square(x)))
+
+
+def spectral_norm(X):
+    """Julia 0.5 `norm(::Matrix)` = induced 2-norm (largest singular value); vectors: 2-norm."""
+    X = np.asarray(X)
+    if X.ndim == 1:
+        return float(np.sqrt(np.sum(X * X)))
+    return float(np.linalg.norm(X, 2))
+
+
+def delta(new, old):
+    """src/util.jl:27-29 -- norm(old-new)/norm(old) with operator 2-norms."""
+    return spectral_norm(old - new) / spectral_norm(old)
+
+
+def traceXTY(X, Y):
+    """src/util.jl:104-106."""
+    return float(np.sum(X * Y))
+
+
+def normalEntropy_matrix_logdet(m, logdet, clamp=True):
+    """src/util.jl:113-125 given log(det Sigma); det is clamped to eps(0.0) from below."""
+    if clamp:
+        logdet = max(logdet, math.log(EPS0))
+    return m / 2 + m / 2 * LN2PI + 0.5 * logdet
+
+
+def normalEntropy_diag(diagSigma):
+    """src/util.jl:133-137."""
+    n = diagSigma.shape[0]
+    return n / 2 + n / 2 * LN2PI + 0.5 * float(np.sum(np.log(diagSigma)))
+
+
+def gammaEntropy(a, b):
+    """src/util.jl:144-146 (verbatim, including the +log(b) sign)."""
+    from scipy.special import digamma, gammaln
+    return a + np.log(b) + gammaln(a) + (1 - a) * digamma(a)
+
+
+def gammaELn(a, b):
+    """src/util.jl:153-155."""
+    from scipy.special import digamma
+    return digamma(a) - np.log(b)
+
+
+# ----------------------------------------------------------------------------------------------
+# basic VBMF  (src/vbmf.jl)
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class vbmf_parameters:
+    """src/vbmf.jl:22-40 -- same field names and order."""
+    L: int = 0
+    M: int = 0
+    H: int = 0
+    H1: int = 0
+    labels: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=np.int64))
+    AHat: Optional[np.ndarray] = None
+    BHat: Optional[np.ndarray] = None
+    SigmaA: Optional[np.ndarray] = None
+    SigmaB: Optional[np.ndarray] = None
+    CA: Optional[np.ndarray] = None
+    CB: Optional[np.ndarray] = None
+    invCA: Optional[np.ndarray] = None
+    invCB: Optional[np.ndarray] = None
+    sigma2: float = 1.0
+    YHat: Optional[np.ndarray] = None
+
+
+def copy_params(p):
+    """src/vbmf.jl:80-88 -- SHALLOW copy: arrays are shared."""
+    q = type(p)()
+    for f in fields(p):
+        setattr(q, f.name, getattr(p, f.name))
+    return q
+
+
+def _mask(AHat, labels, H1):
+    """src/vbmf.jl:61,101 -- AHat[labels, end-H1+1:end] = 0."""
+    if H1 > 0 and len(labels) > 0:
+        AHat[np.asarray(labels, dtype=np.int64), AHat.shape[1] - H1:] = 0.0
+
+
+def vbmf_init(Y, H, ca=1.0, cb=1.0, sigma2=1.0, H1=0, labels=(), rng=None, materialize_yhat=True):
+    """src/vbmf.jl:48-73.  `rng` (np.random.Generator) replaces Julia's global MersenneTwister."""
+    rng = np.random.default_rng(0) if rng is None else rng
+    p = vbmf_parameters()
+    L, M = Y.shape
+    p.L, p.M, p.H, p.H1 = L, M, H, H1
+    p.labels = np.asarray(labels, dtype=np.int64)
+    p.AHat = rng.standard_normal((M, H))
+    _mask(p.AHat, p.labels, H1)
+    p.BHat = rng.standard_normal((L, H))
+    p.SigmaA = np.zeros((H, H))
+    p.SigmaB = np.zeros((H, H))
+    p.CA = ca * np.eye(H)
+    p.CB = cb * np.eye(H)
+    p.invCA = np.linalg.inv(p.CA)
+    p.invCB = np.linalg.inv(p.CB)
+    p.sigma2 = float(sigma2)
+    p.YHat = p.BHat @ p.AHat.T if materialize_yhat else None
+    return p
+
+
+def updateA(Y, p):
+    """src/vbmf.jl:95-102."""
+    p.SigmaA = p.sigma2 * np.linalg.inv(p.BHat.T @ p.BHat + p.L * p.SigmaB + p.sigma2 * p.invCA)
+    p.AHat = ((Y.T @ p.BHat) @ p.SigmaA) / p.sigma2
+    _mask(p.AHat, p.labels, p.H1)
+
+
+def updateB(Y, p):
+    """src/vbmf.jl:109-113."""
+    p.SigmaB = p.sigma2 * np.linalg.inv(p.AHat.T @ p.AHat + p.M * p.SigmaA + p.sigma2 * p.invCB)
+    p.BHat = ((Y @ p.AHat) @ p.SigmaB) / p.sigma2
+
+
+def updateYHat(p):
+    """src/vbmf.jl:120-122."""
+    p.YHat = p.BHat @ p.AHat.T
+
+
+def updateCA(p):
+    """src/vbmf.jl:129-134 -- CA diagonal written in place (Q2), invCA rebound."""
+    for h in range(p.H):
+        p.CA[h, h] = norm2(p.AHat[:, h]) / p.M + p.SigmaA[h, h]
+    p.invCA = np.linalg.inv(p.CA)
+
+
+def updateCB(p):
+    """src/vbmf.jl:141-146."""
+    for h in range(p.H):
+        p.CB[h, h] = norm2(p.BHat[:, h]) / p.L + p.SigmaB[h, h]
+    p.invCB = np.linalg.inv(p.CB)
+
+
+def updateSigma2(Y, p):
+    """src/vbmf.jl:153-157 -- faithful: Y.^2 temporary, 2*Y' temporary, the M x M product."""
+    p.sigma2 = (norm2(Y) - np.trace(((2 * Y.T) @ p.BHat) @ p.AHat.T)
+                + np.trace((p.AHat.T @ p.AHat + p.M * p.SigmaA) @ (p.BHat.T @ p.BHat + p.L * p.SigmaB))
+                ) / (p.L * p.M)
+
+
+def updateSigma2_fused(Y, p, trYY, Q):
+    """Same value as updateSigma2 with tr(Y'BA') = sum((Y A) .* B) and a cached ||Y||^2."""
+    p.sigma2 = (trYY - 2.0 * float(np.sum(Q * p.BHat))
+                + traceXTY(p.AHat.T @ p.AHat + p.M * p.SigmaA, p.BHat.T @ p.BHat + p.L * p.SigmaB)
+                ) / (p.L * p.M)
+
+
+def elbo_basic(Y, p, trYY=None):
+    """Build-defined ELBO of the basic model (the reference has none: SURVEY section 8 row A10).
+
+    Gaussian likelihood/priors/posteriors of src/vbmf.jl:166-170; point estimates CA, CB, sigma2.
+    PARITY UNPINNED.  Undefined (-inf) before the first sweep (SigmaA = SigmaB = 0).
+    """
+    L, M, H = p.L, p.M, p.H
+    trYY = norm2(Y) if trYY is None else trYY
+    GA = p.AHat.T @ p.AHat + M * p.SigmaA
+    GB = p.BHat.T @ p.BHat + L * p.SigmaB
+    resid = trYY - 2.0 * float(np.sum((Y @ p.AHat) * p.BHat)) + traceXTY(GA, GB)
+    ca, cb = np.diag(p.CA), np.diag(p.CB)
+    sA, ldA = np.linalg.slogdet(p.SigmaA)
+    sB, ldB = np.linalg.slogdet(p.SigmaB)
+    if sA <= 0 or sB <= 0:
+        return -math.inf
+    F = -(L * M / 2) * math.log(2 * math.pi * p.sigma2) - resid / (2 * p.sigma2)
+    F += -(M / 2) * float(np.sum(np.log(ca))) - 0.5 * float(np.sum(np.diag(GA) / ca)) + (M / 2) * ldA + M * H / 2
+    F += -(L / 2) * float(np.sum(np.log(cb))) - 0.5 * float(np.sum(np.diag(GB) / cb)) + (L / 2) * ldB + L * H / 2
+    return F
+
+
+def vbmf_(Y, p, niter, eps=1e-6, est_covs=False, est_var=False, fused=False, trace=None):
+    """vbmf! -- src/vbmf.jl:175-231 (logging omitted).  Returns (p, iterations_done, d).
+
+    fused=False follows the reference's operation order and temporaries ("faithful", the timed CPU
+    baseline); fused=True is the algebraically identical two-pass form the GPU computes.
+    `trace`, if a list, receives (d, sigma2, elbo) per sweep.
+    """
+    old = p.BHat                              # :187-188
+    d = eps + 1.0                             # :189
+    i = 1
+    trYY = norm2(Y) if (fused or trace is not None) else None
+    while i <= niter and d > eps:             # :193
+        if fused:
+            GB = p.BHat.T @ p.BHat
+            p.SigmaA = p.sigma2 * np.linalg.inv(GB + p.L * p.SigmaB + p.sigma2 * p.invCA)
+            p.AHat = ((Y.T @ p.BHat) @ p.SigmaA) / p.sigma2
+            _mask(p.AHat, p.labels, p.H1)
+            GA = p.AHat.T @ p.AHat
+            p.SigmaB = p.sigma2 * np.linalg.inv(GA + p.M * p.SigmaA + p.sigma2 * p.invCB)
+            Q = Y @ p.AHat
+            p.BHat = (Q @ p.SigmaB) / p.sigma2
+        else:
+            updateA(Y, p)
+            updateB(Y, p)
+        if est_covs:
+            updateCA(p)
+            updateCB(p)
+        if est_var:
+            if fused:
+                updateSigma2_fused(Y, p, trYY, Q)
+            else:
+                updateSigma2(Y, p)
+        d = delta(p.BHat, old)                # :211
+        old = p.BHat                          # :212
+        if trace is not None:
+            trace.append((d, p.sigma2, elbo_basic(Y, p, trYY)))
+        i += 1
+    return p, i - 1, d
+
+
+def vbmf(Y, p_in, niter, **kw):
+    """src/vbmf.jl:238-248."""
+    p = copy_params(p_in)
+    # the reference's shallow copy shares CA/CB whose diagonals are then written in place (Q2);
+    # copy those two so oracle callers can reuse p_in -- results are unaffected.
+    p.CA, p.CB = p.CA.copy(), p.CB.copy()
+    return vbmf_(Y, p, niter, **kw)
+
+
+def vbls_(Y, p, niter):
+    """examples/mil_util.jl:179-203, vbmf_parameters branch: A/CA/sigma2 sweeps with B frozen."""
+    for _ in range(niter):
+        updateA(Y, p)
+        updateCA(p)
+        updateSigma2(Y, p)
+    return p.AHat
+
+
+# ----------------------------------------------------------------------------------------------
+# ARD-sparse VBMF  (src/vbmf_sparse.jl), diag_var=false only
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class vbmf_sparse_parameters:
+    """src/vbmf_sparse.jl:47-90 (heteroscedastic fields kept for layout; unused: diag_var=false)."""
+    L: int = 0
+    M: int = 0
+    H: int = 0
+    MH: int = 0
+    H1: int = 0
+    labels: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=np.int64))
+    AHat: Optional[np.ndarray] = None
+    ATVecHat: Optional[np.ndarray] = None
+    SigmaATVec: Optional[np.ndarray] = None
+    diagSigmaATVec: Optional[np.ndarray] = None
+    invSigmaATVec: Optional[np.ndarray] = None
+    SigmaA: Optional[np.ndarray] = None
+    BHat: Optional[np.ndarray] = None
+    SigmaB: Optional[np.ndarray] = None
+    CA: Optional[np.ndarray] = None
+    alpha0: float = 1e-10
+    beta0: float = 1e-10
+    alpha: float = 0.0
+    beta: Optional[np.ndarray] = None
+    CB: Optional[np.ndarray] = None
+    gamma0: float = 1e-10
+    delta0: float = 1e-10
+    gamma: float = 0.0
+    delta: Optional[np.ndarray] = None
+    sigmaHat: float = 1.0
+    eta0: float = 1e-10
+    zeta0: float = 1e-10
+    eta: float = 0.0
+    zeta: float = 0.0
+    sigmaVecHat: Optional[np.ndarray] = None
+    etaVec: Optional[np.ndarray] = None
+    zetaVec: Optional[np.ndarray] = None
+    YHat: Optional[np.ndarray] = None
+    trYTY: float = 0.0
+
+
+def vbmf_sparse_init(Y, H, ca=1.0, alpha0=1e-10, beta0=1e-10, cb=1.0, gamma0=1e-10, delta0=1e-10,
+                     sigma=1.0, eta0=1e-10, zeta0=1e-10, H1=0, labels=(), rng=None, full_cov=True,
+                     materialize_yhat=True):
+    """src/vbmf_sparse.jl:101-153.  full_cov=False skips the two eye(MH) allocations (QS8)."""
+    rng = np.random.default_rng(0) if rng is None else rng
+    p = vbmf_sparse_parameters()
+    L, M = Y.shape
+    p.L, p.M, p.H, p.MH, p.H1 = L, M, H, M * H, H1
+    p.labels = np.asarray(labels, dtype=np.int64)
+    p.AHat = rng.standard_normal((M, H))
+    _mask(p.AHat, p.labels, H1)
+    p.ATVecHat = p.AHat.reshape(M * H).copy()          # vec(A'), index m*H+h  (:119)
+    p.SigmaATVec = np.eye(M * H) if full_cov else None
+    p.diagSigmaATVec = np.ones(M * H)
+    p.invSigmaATVec = np.eye(M * H) if full_cov else None
+    p.SigmaA = np.zeros((H, H))
+    p.BHat = rng.standard_normal((L, H))
+    p.SigmaB = np.zeros((H, H))
+    p.CA = ca * np.ones(M * H)
+    p.alpha0, p.beta0 = alpha0, beta0
+    p.alpha = alpha0 + 0.5
+    p.beta = beta0 * np.ones(M * H)
+    p.CB = cb * np.ones(H)
+    p.gamma0, p.delta0 = gamma0, delta0
+    p.gamma = gamma0 + L / 2
+    p.delta = delta0 * np.ones(H)
+    p.sigmaHat = float(sigma)
+    p.eta0, p.zeta0 = eta0, zeta0
+    p.eta = eta0 + L * M / 2
+    p.zeta = zeta0
+    p.sigmaVecHat = sigma * np.ones(L)
+    p.etaVec = (eta0 + M / 2) * np.ones(L)
+    p.zetaVec = zeta0 * np.ones(L)
+    p.YHat = p.BHat @ p.AHat.T if materialize_yhat else None
+    p.trYTY = traceXTY(Y, Y)
+    return p
+
+
+def spread_v(v, M, reference_compat=True):
+    """The H-vector -> M*H expansion of src/vbmf_sparse.jl:221.
+
+    reference_compat=True reproduces `repeat(v, inner=M-1)` after the first H entries (QS1):
+    position p >= H uses v[(p-H) // (M-1)].  False = the consistent tiling v[p % H].
+    """
+    H = v.shape[0]
+    if reference_compat:
+        return np.concatenate([v, np.repeat(v, M - 1)])
+    return np.tile(v, M)
+
+
+def sparse_updateA(Y, p, full_cov=False, reference_compat=True):
+    """src/vbmf_sparse.jl:176-247, diag_var=false branches."""
+    L, M, H = p.L, p.M, p.H
+    if full_cov:                                                    # :178-202
+        K = p.sigmaHat * (p.BHat.T @ p.BHat + L * p.SigmaB)
+        p.invSigmaATVec = np.kron(np.eye(M), K) + np.diag(p.CA)
+        p.SigmaATVec = np.linalg.inv(p.invSigmaATVec)
+        p.diagSigmaATVec = np.diag(p.SigmaATVec).copy()
+        BtY = p.BHat.T @ Y                                          # H x M; vec = column-major
+        p.ATVecHat = p.sigmaHat * (p.SigmaATVec @ BtY.T.reshape(M * H))
+        p.SigmaA = np.zeros((H, H))
+        for m in range(M):
+            p.SigmaA += p.SigmaATVec[m * H:(m + 1) * H, m * H:(m + 1) * H]
+    else:                                                           # :204-240
+        v = p.sigmaHat * np.sum(p.BHat * p.BHat, axis=0) + L * np.diag(p.SigmaB)   # :217 (QS2)
+        prec = spread_v(v, M, reference_compat) + p.CA             # :221-223
+        p.diagSigmaATVec = 1.0 / prec                               # :226
+        BtY = p.BHat.T @ Y
+        p.ATVecHat = p.sigmaHat * p.diagSigmaATVec * BtY.T.reshape(M * H)           # :232
+        p.SigmaA = np.diag(p.diagSigmaATVec.reshape(M, H).sum(axis=0))              # :236-239
+    p.AHat = p.ATVecHat.reshape(M, H).copy()                        # :244
+    _mask(p.AHat, p.labels, p.H1)                                   # :245
+    p.ATVecHat = p.AHat.reshape(M * H).copy()                       # :246
+
+
+def sparse_updateB(Y, p):
+    """src/vbmf_sparse.jl:263-266."""
+    p.SigmaB = np.linalg.inv(np.diag(p.CB) + p.sigmaHat * (p.AHat.T @ p.AHat + p.SigmaA))
+    p.BHat = p.sigmaHat * ((Y @ p.AHat) @ p.SigmaB)
+
+
+def sparse_updateCA(p):
+    """src/vbmf_sparse.jl:284-288."""
+    p.beta = p.beta0 + 0.5 * (p.ATVecHat * p.ATVecHat + p.diagSigmaATVec)
+    p.CA = p.alpha / p.beta
+
+
+def sparse_updateCB(p):
+    """src/vbmf_sparse.jl:295-300."""
+    p.delta = p.delta0 + 0.5 * np.sum(p.BHat * p.BHat, axis=0) + 0.5 * np.diag(p.SigmaB)
+    p.CB = p.gamma / p.delta
+
+
+def sparse_updateSigma(Y, p):
+    """src/vbmf_sparse.jl:317-321."""
+    p.zeta = (p.zeta0 + 0.5 * p.trYTY - traceXTY(p.BHat, Y @ p.AHat)
+              + 0.5 * traceXTY(p.AHat.T @ p.AHat + p.SigmaA, p.BHat.T @ p.BHat + p.L * p.SigmaB))
+    p.sigmaHat = p.eta / p.zeta
+
+
+def vbmf_sparse_(Y, p, niter, eps=1e-6, full_cov=False, est_cb=True, reference_compat=True, trace=None):
+    """vbmf_sparse! -- src/vbmf_sparse.jl:344-410 (diag_var=false).  Returns (d, iterations)."""
+    old = p.BHat.copy()
+    d = eps + 1.0
+    i = 1
+    while i <= niter and d > eps:
+        sparse_updateA(Y, p, full_cov=full_cov, reference_compat=reference_compat)
+        sparse_updateB(Y, p)
+        sparse_updateCA(p)
+        if est_cb:
+            sparse_updateCB(p)
+        sparse_updateSigma(Y, p)
+        d = delta(p.BHat, old)
+        old = p.BHat.copy()
+        if trace is not None:
+            trace.append((d, p.sigmaHat))
+        i += 1
+    return d, i - 1
+
+
+def lowerBound(Y, p, clamp=True):
+    """src/vbmf_sparse.jl:435-471, verbatim quirks QS4; H(B) restated as L*logdet(SigmaB) (QS5)."""
+    from scipy.special import gammaln
+    L_, M, H = p.L, p.M, p.H
+    MH = p.ATVecHat.shape[0]
+    Lb = 0.0
+    Lb += -L_ * M / 2 * LN2PI + L_ * M / 2 * gammaELn(p.eta, p.zeta)
+    Lb += -p.sigmaHat / 2 * (p.trYTY - 2 * traceXTY(p.BHat, Y @ p.AHat)
+                             + traceXTY(p.AHat.T @ p.AHat + p.SigmaA, p.BHat.T @ p.BHat + L_ * p.SigmaB))
+    eln_ca = gammaELn(p.alpha, p.beta)
+    Lb += -MH / 2 * LN2PI + 0.5 * float(np.sum(eln_ca))
+    Lb += -0.5 * float(p.CA @ (p.ATVecHat ** 2 + p.diagSigmaATVec))
+    Lb += -L_ * H / 2 * LN2PI
+    eln_cb = gammaELn(p.gamma, p.delta)
+    Lb += L_ / 2 * float(np.sum(eln_cb))
+    Lb += -0.5 * traceXTY(np.diag(p.CB), p.BHat.T @ p.BHat + L_ * p.SigmaB)
+    Lb += p.eta0 * math.log(p.zeta0) - gammaln(p.eta0)
+    Lb += (p.eta0 - 1) * gammaELn(p.eta, p.zeta) - p.zeta0 * p.sigmaHat
+    Lb += MH * (p.alpha0 * math.log(p.beta0) - gammaln(p.alpha0))
+    Lb += (p.alpha0 - 1) * float(np.sum(eln_ca))
+    Lb += -p.beta0 * float(np.sum(p.CA))
+    Lb += H * (p.gamma0 * math.log(p.delta0) - gammaln(p.gamma0))
+    Lb += (p.gamma0 - 1) * float(np.sum(eln_cb))
+    Lb += -p.gamma0 * float(np.sum(p.CB))                           # sic: gamma0 (QS4)
+    Lb += normalEntropy_diag(p.diagSigmaATVec)
+    sgn, ld = np.linalg.slogdet(p.SigmaB)
+    logdet_kron = L_ * ld if sgn > 0 else -math.inf                 # det(kron(SigmaB, I_L)) = det(SigmaB)^L
+    Lb += normalEntropy_matrix_logdet(L_ * H, logdet_kron, clamp=clamp)
+    Lb += float(gammaEntropy(p.eta, p.zeta))
+    Lb += float(np.sum(gammaEntropy(p.alpha, p.beta)))
+    Lb += float(np.sum(gammaEntropy(p.gamma, p.delta)))
+    return float(Lb)
+
+
+# ----------------------------------------------------------------------------------------------
+# synthetic data (generalises toy_matrix, examples/toy_data.jl:7-18)
+# ----------------------------------------------------------------------------------------------
+def toy_matrix(L, M, H, std, rng):
+    B = rng.standard_normal((L, H))
+    A = np.zeros((M, H))
+    A[np.arange(M), rng.integers(0, H, size=M)] = 1.0
+    Y = B @ A.T + std * rng.standard_normal((L, M))
+    return Y, A, B
