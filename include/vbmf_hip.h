@@ -1,0 +1,141 @@
+/*
+ * vbmf_hip.h -- C ABI of the MI355X-native VB matrix-factorization sweep.
+ *
+ * The reference (vitskvara/VBMatrixFactorization.jl) has no FFI layer: its boundary for this path is
+ * the Julia call surface of src/vbmf.jl.  Each entry point below names the reference interface it
+ * replaces (file:line relative to the reference root).  A Julia host `ccall`s these (see
+ * INTEGRATION.md and vbmatrixfactorization.jl_amd/julia/VBMatrixFactorizationHIP.jl); the tested
+ * twin is the Python ctypes host in vbmatrixfactorization.jl_amd/.
+ *
+ * Conventions
+ *   - extern "C", no exceptions cross the boundary.  Every function returns 0 on success or a
+ *     negative vbmf_status; vbmf_last_error(ctx) gives the message (Julia `error(...)` analogue).
+ *   - All matrices at the boundary are `double`, COLUMN-MAJOR, leading dimension >= rows (Julia
+ *     Array{Float64,2} memory as is).  Indices are 0-based (the Julia wrapper subtracts 1 from labels).
+ *   - Every pointer is borrowed for the duration of the call; the library copies in/out and never
+ *     retains host pointers.  One ctx = one problem (one row-shard of it when nranks > 1) on one GPU;
+ *     a ctx is not thread-safe, distinct ctxs are independent.
+ *   - There is NO CPU fallback: vbmf_create fails (VBMF_ERR_NO_DEVICE) without a gfx950 device.
+ */
+#ifndef VBMF_HIP_H
+#define VBMF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vbmf_ctx vbmf_ctx;
+
+typedef enum {
+    VBMF_OK = 0,
+    VBMF_ERR_INVALID = -1,     /* bad argument / shape / state */
+    VBMF_ERR_NO_DEVICE = -2,   /* no usable HIP device (no CPU fallback exists) */
+    VBMF_ERR_HIP = -3,         /* a HIP runtime call failed */
+    VBMF_ERR_NUMERIC = -4,     /* non-positive pivot / non-finite value in the H x H algebra */
+    VBMF_ERR_COMM = -5,        /* RCCL failure */
+    VBMF_ERR_UNSUPPORTED = -6
+} vbmf_status;
+
+/* storage of Y on the device / arithmetic of the two streaming contractions */
+#define VBMF_Y_F32 0           /* Y fp32, exact-f32 MFMA (v_mfma_f32_32x32x2_f32) */
+#define VBMF_Y_BF16 1          /* Y bf16, v_mfma_f32_32x32x16_bf16, fp32 accumulate */
+/* factor operand (BHat in Y'B, AHat in Y*A) fed to the MFMA */
+#define VBMF_FACTOR_AUTO 0     /* f32 with f32 Y; bf16x2 with bf16 Y */
+#define VBMF_FACTOR_BF16 1     /* one bf16 rounding of the factor */
+#define VBMF_FACTOR_BF16X2 2   /* hi+lo bf16 split (two MFMAs), ~16 mantissa bits */
+
+#define VBMF_VARIANT_BASIC 0        /* src/vbmf.jl */
+#define VBMF_VARIANT_SPARSE_DIAG 1  /* src/vbmf_sparse.jl, full_cov=false, diag_var=false */
+
+/* reference_compat bits (default: all set = behave like the reference) */
+#define VBMF_COMPAT_SPECTRAL_DELTA 1u  /* d uses operator 2-norms (src/util.jl:27-29, Julia 0.5 norm) */
+#define VBMF_COMPAT_SPARSE_REPEAT 2u   /* repeat(v, inner=M-1) layout of src/vbmf_sparse.jl:221 */
+#define VBMF_COMPAT_DEFAULT 0xFFFFFFFFu
+
+typedef struct {
+    int32_t struct_size;       /* = sizeof(vbmf_opts); for ABI evolution */
+    int32_t device;            /* HIP device ordinal */
+    int32_t y_dtype;           /* VBMF_Y_* */
+    int32_t factor_dtype;      /* VBMF_FACTOR_* */
+    int32_t variant;           /* VBMF_VARIANT_* */
+    uint32_t reference_compat; /* VBMF_COMPAT_* bitmask */
+    int32_t nranks;            /* row-shards of Y (one process per GPU); 1 = single GPU */
+    int32_t rank;
+    int64_t L_global;          /* total rows over all ranks (0 => = L) */
+    int64_t row_offset;        /* first global row owned by this ctx */
+    int32_t pass1_splits;      /* split-K factor of the Y'B pass; 0 = auto */
+    int32_t reserved;
+} vbmf_opts;
+
+/* update selectors for vbmf_step -- one bit per reference update function */
+#define VBMF_STEP_A 1       /* updateA!      src/vbmf.jl:95-102 */
+#define VBMF_STEP_B 2       /* updateB!      src/vbmf.jl:109-113 */
+#define VBMF_STEP_CA 4      /* updateCA!     src/vbmf.jl:129-134 */
+#define VBMF_STEP_CB 8      /* updateCB!     src/vbmf.jl:141-146 */
+#define VBMF_STEP_SIGMA2 16 /* updateSigma2! src/vbmf.jl:153-157 */
+
+void vbmf_default_opts(vbmf_opts* o);
+
+/* One problem of L (local) x M with rank H.  Replaces the allocation half of vbmf_init
+ * (src/vbmf.jl:48-73); the random draw stays on the host side. */
+int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts* opts);
+int vbmf_destroy(vbmf_ctx* ctx);
+const char* vbmf_last_error(const vbmf_ctx* ctx); /* ctx may be NULL: error of a failed create */
+
+/* Upload this rank's rows of Y (L x M, column-major, ld >= L): converts to the device dtype, builds
+ * the two MFMA-fragment-tiled copies and caches ||Y||_F^2 (of the values as stored).  Replaces the
+ * `Y::Array{Float64,2}` argument of vbmf!/updateA!/updateB!/updateSigma2! (src/vbmf.jl:95,109,153,175). */
+int vbmf_set_Y(vbmf_ctx* ctx, const double* Y, int64_t ldY);
+/* Device-side generator of the toy model (examples/toy_data.jl:7-18): Y = B* A*' + noise_std*N(0,1),
+ * A* one-hot rows over Hstar columns, values rounded to the device dtype; counter-based, so the
+ * matrix does not depend on nranks. */
+int vbmf_set_Y_synthetic(vbmf_ctx* ctx, uint64_t seed, int64_t Hstar, double noise_std);
+/* Read back Y exactly as stored on the device (rows [row0,row0+nrows) of this rank, column-major). */
+int vbmf_get_Y(vbmf_ctx* ctx, double* Y, int64_t ldY, int64_t row0, int64_t nrows);
+int vbmf_get_trYY(vbmf_ctx* ctx, double* trYY);
+
+/* State = the numeric fields of `vbmf_parameters` (src/vbmf.jl:22-40).  AHat is M x H (ldA >= M),
+ * BHat is L x H (this rank's rows, ldB >= L), SigmaA/SigmaB are H x H (ld = H), CA/CB are passed as
+ * their diagonals (length H; the reference keeps them diagonal by construction, src/vbmf.jl:65-66,131,143).
+ * labels0: 0-based rows of AHat whose last H1 columns are forced to zero (src/vbmf.jl:61,101). */
+int vbmf_set_state(vbmf_ctx* ctx, const double* AHat, int64_t ldA, const double* BHat, int64_t ldB,
+                   const double* SigmaA, const double* SigmaB, const double* CA_diag, const double* CB_diag,
+                   double sigma2, const int64_t* labels0, int64_t nlabels, int64_t H1);
+int vbmf_get_state(vbmf_ctx* ctx, double* AHat, int64_t ldA, double* BHat, int64_t ldB, double* SigmaA,
+                   double* SigmaB, double* CA_diag, double* CB_diag, double* sigma2);
+
+/* Apply the selected reference updates once, in the reference's order A, B, CA, CB, SIGMA2
+ * (src/vbmf.jl:194-204).  For callers that drive the updates themselves (examples/mil_util.jl:183-185). */
+int vbmf_step(vbmf_ctx* ctx, int which);
+
+/* The vbmf! loop (src/vbmf.jl:187-214): while i <= niter && d > eps { A; B; [CA; CB]; [sigma2]; d }.
+ * Runs entirely on the device; the stop test is evaluated device-side so the state freezes exactly
+ * where the reference would stop.  iters_done = i-1 (src/vbmf.jl:221), d_last = last d.
+ * trace (optional, niter x 4 doubles, row-major): per sweep d, sigma2, elbo, reserved. */
+int vbmf_run(vbmf_ctx* ctx, int64_t niter, double eps, int est_covs, int est_var, int64_t* iters_done,
+             double* d_last, double* trace);
+
+/* updateYHat! (src/vbmf.jl:120-122) on demand: YHat = BHat*AHat' (L x M column-major). */
+int vbmf_get_YHat(vbmf_ctx* ctx, double* YHat, int64_t ld);
+/* Build-defined ELBO of the basic model (the reference has none). */
+int vbmf_elbo(vbmf_ctx* ctx, double* elbo);
+
+/* ---- multi-GPU: one process per GPU, Y row-sharded, RCCL all-reduce of Y'B and of the Grams ---- */
+#define VBMF_UNIQUE_ID_BYTES 128
+int vbmf_comm_unique_id(void* id128);                       /* rank 0 creates, host broadcasts */
+int vbmf_comm_init(vbmf_ctx* ctx, const void* id128);       /* collective over all nranks ctxs */
+
+/* ---- measurement hooks (bench.py): HIP-event timing of the two streaming kernels ---- */
+int vbmf_profile_enable(vbmf_ctx* ctx, int on);
+/* out[0]=ms in Y'B pass, out[1]=launches, out[2]=ms in Y*A pass, out[3]=launches, out[4..7] reserved */
+int vbmf_profile_read(vbmf_ctx* ctx, double* out8, int reset);
+/* algorithmic bytes one launch of pass p (1|2) moves: Y once + factor in + result out */
+int vbmf_pass_bytes(vbmf_ctx* ctx, int pass, double* bytes);
+int vbmf_device_sync(vbmf_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VBMF_HIP_H */

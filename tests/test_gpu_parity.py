@@ -1,0 +1,250 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the fp64 oracle on identical inputs.
+
+Tolerances (stated per dtype; floating-point work, so not bit-exact):
+  f32 path   (Y fp32, exact-f32 MFMA, fp32 accumulate):   factors/covariances 2e-5 rel-Frobenius per update
+  bf16x2     (Y bf16 as stored, factor hi+lo bf16):       1e-4 against the oracle fed the SAME stored Y
+  bf16       (factor single bf16):                        5e-3
+The H x H algebra is fp64 on the device; sigma2 suffers the reference's own cancellation
+(||Y||^2 - 2tr + tr ~ noise/signal), so its tolerance is looser by that factor.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as G
+from oracle import vbmf_oracle as O
+from tests.helpers import clone_oracle, compare, relF, report, to_pkg_params
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    G.build()
+    return G.load_package()
+
+
+TOL_F32 = dict(default=2e-5, sigma2=2e-4)
+TOL_X2 = dict(default=1e-4, sigma2=1e-3)
+TOL_BF16 = dict(default=5e-3, sigma2=2e-2)
+
+
+def _problem(L, M, H, seed, **kw):
+    rng = np.random.default_rng(seed)
+    Y, _, _ = O.toy_matrix(L, M, max(1, min(H, 8)), 0.05, rng)
+    po = O.vbmf_init(Y, H, ca=0.1, cb=0.1, sigma2=0.1, rng=np.random.default_rng(seed + 1), materialize_yhat=False, **kw)
+    return Y, po
+
+
+# ---- data path ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("ydt", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(10, 20), (203, 97), (64, 64), (1000, 333)])
+def test_tile_roundtrip(pkg, ydt, shape):
+    """set_Y -> two tiled device copies -> get_Y returns Y rounded to the device dtype, bit for bit."""
+    L, M = shape
+    rng = np.random.default_rng(7)
+    Y = rng.standard_normal((L, M)) * np.exp(rng.uniform(-3, 3, size=(L, 1)))
+    with pkg.capi.Context(L, M, 3, y_dtype=pkg.VBMF_Y_F32 if ydt == "f32" else pkg.VBMF_Y_BF16) as c:
+        c.set_Y(Y)
+        back = c.get_Y()
+        if ydt == "f32":
+            want = Y.astype(np.float32).astype(np.float64)
+        else:
+            import struct
+            u = Y.astype(np.float32).view(np.uint32).astype(np.uint64)
+            u = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16          # RNE to bf16 (finite inputs)
+            want = u.astype(np.uint32).view(np.float32).astype(np.float64)
+        assert np.array_equal(back, want)
+        assert abs(c.trYY() - float(np.sum(want * want))) <= 1e-12 * float(np.sum(want * want))
+        # partial read-back of a row range
+        if L > 40:
+            sub = c.get_Y(row0=17, nrows=20)
+            assert np.array_equal(sub, want[17:37])
+
+
+# ---- per-update parity (no error accumulation: every update starts from the oracle's state) ------
+@pytest.mark.parametrize("L,M,H", [(10, 20, 2), (200, 100, 5), (203, 97, 33), (500, 260, 40), (300, 180, 100)])
+def test_each_update_f32(pkg, L, M, H):
+    Y, po = _problem(L, M, H, 100 + H)
+    pkg.set_defaults(y_dtype=pkg.VBMF_Y_F32, factor_dtype=pkg.VBMF_FACTOR_AUTO)
+    Yf = Y.astype(np.float32).astype(np.float64)                     # identical inputs: Y as stored
+    for sweep in range(3):
+        pg = to_pkg_params(pkg, po)
+        pkg.updateA_(Yf, pg); O.updateA(Yf, po)
+        compare(f"f32 {L}x{M} H{H} s{sweep} updateA", pg, po, TOL_F32, fields=("AHat", "SigmaA"))
+        pg = to_pkg_params(pkg, po)
+        pkg.updateB_(Yf, pg); O.updateB(Yf, po)
+        compare(f"f32 {L}x{M} H{H} s{sweep} updateB", pg, po, TOL_F32, fields=("BHat", "SigmaB"))
+        pg = to_pkg_params(pkg, po)
+        pkg.updateCA_(pg, Y=Yf); pkg.updateCB_(pg, Y=Yf); O.updateCA(po); O.updateCB(po)
+        compare(f"f32 {L}x{M} H{H} s{sweep} updateC", pg, po, TOL_F32, fields=("CA", "CB", "invCA", "invCB"))
+        pg = to_pkg_params(pkg, po)
+        pkg.updateSigma2_(Yf, pg); O.updateSigma2(Yf, po)
+        compare(f"f32 {L}x{M} H{H} s{sweep} updateSigma2", pg, po, TOL_F32, fields=())
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x2", "bf16"])
+@pytest.mark.parametrize("L,M,H", [(10, 20, 2), (640, 384, 16), (777, 555, 64)])
+def test_run_trajectory(pkg, mode, L, M, H):
+    """vbmf! for 12 sweeps with est_covs=est_var=true against the oracle fed the SAME stored Y."""
+    Y, po = _problem(L, M, H, 300 + H)
+    ydt = pkg.VBMF_Y_F32 if mode == "f32" else pkg.VBMF_Y_BF16
+    fdt = {"f32": pkg.VBMF_FACTOR_AUTO, "bf16x2": pkg.VBMF_FACTOR_BF16X2, "bf16": pkg.VBMF_FACTOR_BF16}[mode]
+    tol = {"f32": TOL_F32, "bf16x2": TOL_X2, "bf16": TOL_BF16}[mode]
+    with pkg.capi.Context(L, M, H, y_dtype=ydt, factor_dtype=fdt) as c:
+        c.set_Y(Y)
+        Ys = np.ascontiguousarray(c.get_Y())
+    pkg.set_defaults(y_dtype=ydt, factor_dtype=fdt)
+    pg = to_pkg_params(pkg, po)
+    pkg.vbmf_(Ys, pg, 12, eps=0.0, est_covs=True, est_var=True)
+    _, n, d = O.vbmf_(Ys, po, 12, eps=0.0, est_covs=True, est_var=True)
+    scale = 8.0                                                       # 12 sweeps of accumulated rounding
+    tol12 = {k: v * scale for k, v in tol.items()}
+    compare(f"{mode} {L}x{M} H{H} run12", pg, po, tol12)
+    assert pg._last_run[0] == 12
+    assert abs(pg._last_run[1] - d) <= 5e-3 * d + 1e-12, (pg._last_run, d)
+    assert relF(pg.YHat, po.BHat @ po.AHat.T) < 50 * tol["default"]
+
+
+def test_golden_fixture_trajectory(pkg, golden_dir):
+    """The reference's own recorded run (examples/data/vbmf_test): 100 sweeps on the device (f32 path)
+    against the recorded slices."""
+    g = np.load(os.path.join(golden_dir, "vbmf_test.npz"))
+    Y = g["Y"]
+    pkg.set_defaults(y_dtype=pkg.VBMF_Y_F32, factor_dtype=pkg.VBMF_FACTOR_AUTO)
+    p = pkg.vbmf_parameters()
+    p.L, p.M, p.H, p.H1 = 10, 20, 2, 0
+    for f in ("AHat", "BHat", "SigmaA", "SigmaB", "CA", "CB", "invCA", "invCB"):
+        setattr(p, f, g[f][0].copy())
+    p.sigma2 = float(g["sigma2"][0])
+    worst = 0.0
+    for t in (1, 2, 3, 10, 50, 100):
+        done = {1: 0, 2: 1, 3: 2, 10: 3, 50: 10, 100: 50}[t]
+        pkg.vbmf_(Y, p, t - done, eps=0.0, est_covs=True, est_var=True)
+        for f in ("AHat", "BHat", "SigmaA", "SigmaB", "CA", "CB"):
+            e = relF(getattr(p, f), g[f][t]); worst = max(worst, e)
+            assert e < 2e-3, (t, f, e)
+        e = abs(p.sigma2 - g["sigma2"][t]) / g["sigma2"][t]; worst = max(worst, e)
+        assert e < 5e-3, (t, e)
+    report(f"golden vbmf_test f32 100 sweeps worst rel err {worst:.2e}")
+    # Y here is fp64 -> fp32 on upload: not bit-identical inputs, hence the 2e-3 bound after 100 sweeps
+
+
+def test_label_mask(pkg):
+    """AHat[labels, end-H1+1:end] = 0 after every A update (src/vbmf.jl:101)."""
+    Y, po = _problem(120, 90, 6, 41, H1=2, labels=[0, 5, 17, 89])
+    pkg.set_defaults(y_dtype=pkg.VBMF_Y_F32)
+    Yf = Y.astype(np.float32).astype(np.float64)
+    pg = to_pkg_params(pkg, po)
+    pkg.vbmf_(Yf, pg, 6, eps=0.0, est_covs=True, est_var=True)
+    O.vbmf_(Yf, po, 6, eps=0.0, est_covs=True, est_var=True)
+    assert np.all(pg.AHat[[0, 5, 17, 89], 4:] == 0.0) and np.all(pg.AHat[[0, 5, 17, 89], :4] != 0.0)
+    compare("mask run6", pg, po, {k: 5 * v for k, v in TOL_F32.items()})
+
+
+def test_termination_matches_oracle(pkg):
+    """Loop test `i <= niter && d > eps` evaluated on the device: same stopping sweep, frozen state."""
+    Y, po = _problem(150, 80, 3, 77)
+    pkg.set_defaults(y_dtype=pkg.VBMF_Y_F32)
+    Yf = Y.astype(np.float32).astype(np.float64)
+    pg = to_pkg_params(pkg, po)
+    tr = []
+    _, n, d = O.vbmf_(Yf, po, 400, eps=1e-4, est_covs=True, est_var=True, trace=tr)
+    assert 3 < n < 400
+    pkg.vbmf_(Yf, pg, 400, eps=1e-4, est_covs=True, est_var=True)
+    # d crosses eps steeply relative to fp32 noise only if the trajectory is not flat there: allow +-1
+    assert abs(pg._last_run[0] - n) <= 1, (pg._last_run, n, d)
+    assert pg._last_run[1] <= 1e-4
+    compare("termination", pg, po, {k: 50 * v for k, v in TOL_F32.items()})
+    # niter = 0: nothing happens (src/vbmf.jl:193)
+    pg2 = to_pkg_params(pkg, po)
+    pkg.vbmf_(Yf, pg2, 0)
+    assert pg2._last_run[0] == 0 and relF(pg2.BHat, po.BHat) < 1e-6
+
+
+def test_fixed_basis_flow(pkg):
+    """vbls! (examples/mil_util.jl:179-203): updateA!, updateCA!, updateSigma2! with B frozen."""
+    Y, po = _problem(160, 70, 4, 9)
+    pkg.set_defaults(y_dtype=pkg.VBMF_Y_F32)
+    Yf = Y.astype(np.float32).astype(np.float64)
+    O.vbmf_(Yf, po, 5, eps=0.0, est_covs=True, est_var=True)
+    pg = to_pkg_params(pkg, po)
+    B0 = po.BHat.copy()
+    for _ in range(4):
+        pkg.updateA_(Yf, pg); pkg.updateCA_(pg, Y=Yf); pkg.updateSigma2_(Yf, pg)
+    O.vbls_(Yf, po, 4)
+    assert relF(pg.BHat, B0) < 1e-6
+    compare("vbls 4 iters", pg, po, {k: 4 * v for k, v in TOL_F32.items()})
+
+
+def test_elbo_and_trace(pkg):
+    Y, po = _problem(140, 60, 3, 55)
+    Yf = Y.astype(np.float32).astype(np.float64)
+    with pkg.capi.Context(140, 60, 3, y_dtype=pkg.VBMF_Y_F32) as c:
+        c.set_Y(Yf)
+        c.set_state(po.AHat, po.BHat, po.SigmaA, po.SigmaB, np.diag(po.CA), np.diag(po.CB), po.sigma2)
+        it, d, tr = c.run(8, eps=0.0, est_covs=True, est_var=True, want_trace=True)
+        otr = []
+        O.vbmf_(Yf, po, 8, eps=0.0, est_covs=True, est_var=True, trace=otr)
+        otr = np.array(otr)
+        assert it == 8 and tr.shape == (8, 4)
+        assert np.allclose(tr[:, 0], otr[:, 0], rtol=5e-3)             # d
+        assert np.allclose(tr[:, 1], otr[:, 1], rtol=1e-3)             # sigma2
+        assert np.allclose(tr[:, 2], otr[:, 2], rtol=1e-4, atol=1e-2)  # ELBO (build-defined; parity unpinned)
+        e = c.elbo()
+        assert abs(e - otr[-1, 2]) <= 1e-4 * abs(otr[-1, 2]) + 1e-2
+        report(f"elbo gpu {e:.6f} oracle {otr[-1, 2]:.6f}")
+
+
+def test_synthetic_generator(pkg):
+    """Device generator: shard-independent (a row shard equals the same rows of the full matrix),
+    toy_matrix statistics (examples/toy_data.jl:7-18)."""
+    L, M, Hs = 512, 300, 4
+    with pkg.capi.Context(L, M, 4) as c:
+        c.set_Y_synthetic(1234, Hs, 0.05)
+        Yfull = c.get_Y()
+    with pkg.capi.Context(200, M, 4, L_global=L, row_offset=137, nranks=1) as c:
+        pass
+    # shard as its own ctx (nranks stays 1 here; row_offset only shifts the generator's global row)
+    o = dict(L_global=0, row_offset=137)
+    with pkg.capi.Context(200, M, 4, **o) as c:
+        c.set_Y_synthetic(1234, Hs, 0.05)
+        Yshard = c.get_Y()
+    assert np.array_equal(Yshard, Yfull[137:337])
+    # each column is one of Hs latent columns + small noise: column clusters
+    C = np.corrcoef(Yfull.T)
+    frac_high = np.mean(np.abs(C) > 0.9)
+    assert 0.15 < frac_high < 0.5
+    assert abs(Yfull.std() - 1.0) < 0.15
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x2"])
+def test_config2_shape_three_sweeps(pkg, mode):
+    """BASELINE config 2 shape (10k x 1k, H=32), 3 sweeps, data generated on the device."""
+    L, M, H = 10000, 1000, 32
+    ydt = pkg.VBMF_Y_F32 if mode == "f32" else pkg.VBMF_Y_BF16
+    rng = np.random.default_rng(20170103)
+    A0, B0 = rng.standard_normal((M, H)), rng.standard_normal((L, H))
+    with pkg.capi.Context(L, M, H, y_dtype=ydt) as c:
+        c.set_Y_synthetic(20170101, H, 0.05)
+        Ys = np.ascontiguousarray(c.get_Y())
+        c.set_state(A0, B0, np.zeros((H, H)), np.zeros((H, H)), 0.1 * np.ones(H), 0.1 * np.ones(H), 0.1)
+        it, d, tr = c.run(3, eps=0.0, est_covs=True, est_var=True, want_trace=True)
+        s = c.get_state()
+    po = O.vbmf_parameters()
+    po.L, po.M, po.H = L, M, H
+    po.AHat, po.BHat = A0.copy(), B0.copy()
+    po.SigmaA = np.zeros((H, H)); po.SigmaB = np.zeros((H, H))
+    po.CA = 0.1 * np.eye(H); po.CB = 0.1 * np.eye(H); po.invCA = 10 * np.eye(H); po.invCB = 10 * np.eye(H)
+    po.sigma2 = 0.1
+    otr = []
+    O.vbmf_(Ys, po, 3, eps=0.0, est_covs=True, est_var=True, fused=True, trace=otr)
+    tol = TOL_F32 if mode == "f32" else TOL_X2
+    errs = dict(A=relF(s["AHat"], po.AHat), B=relF(s["BHat"], po.BHat), SA=relF(s["SigmaA"], po.SigmaA),
+                SB=relF(s["SigmaB"], po.SigmaB), ca=relF(s["CA_diag"], np.diag(po.CA)),
+                cb=relF(s["CB_diag"], np.diag(po.CB)), s2=abs(s["sigma2"] - po.sigma2) / po.sigma2,
+                d=abs(d - otr[-1][0]) / otr[-1][0], elbo=abs(tr[-1, 2] - otr[-1][2]) / abs(otr[-1][2]))
+    report(f"cfg2 {mode}: " + " ".join(f"{k}={v:.2e}" for k, v in errs.items()))
+    assert max(errs[k] for k in ("A", "B", "SA", "SB", "ca", "cb")) < 4 * tol["default"], errs
+    assert errs["s2"] < 4 * tol["sigma2"] and errs["d"] < 5e-3 and errs["elbo"] < 1e-4, errs

@@ -1,0 +1,277 @@
+"""MI355X-native drop-in for the VB matrix-factorization sweep of vitskvara/VBMatrixFactorization.jl.
+
+Host-side mirror of the reference's Julia surface for this path (src/vbmf.jl), over the C ABI in
+include/vbmf_hip.h (hand-written HIP kernels for gfx950).  Names follow the reference; Julia's `!`
+becomes a trailing underscore:
+
+    reference (src/vbmf.jl)                      here
+    ------------------------------------------  ------------------------------
+    type vbmf_parameters            :22-40       class vbmf_parameters (same field names/order)
+    vbmf_init(Y, H; ca, cb, sigma2, H1, labels)  vbmf_init(...)            :48-73
+    copy(params)                    :80-88       copy(params)   (shallow, like the reference)
+    updateA!/updateB!               :95-113      updateA_/updateB_
+    updateYHat!                     :120-122     updateYHat_
+    updateCA!/updateCB!             :129-146     updateCA_/updateCB_
+    updateSigma2!                   :153-157     updateSigma2_
+    vbmf!(Y, params, niter; eps, est_covs, est_var, logdir, desc, verb)   vbmf_(...)   :175-231
+    vbmf(Y, params_in, niter; ...)  :238-248     vbmf(...)
+
+`labels` are 1-based row indices of AHat exactly as in the reference struct; they are converted to
+0-based at the C boundary.  Arrays are float64; Y is (L, M), AHat (M, H), BHat (L, H).
+
+There is no CPU implementation in this package: every numeric update runs in libvbmf_hip.so, and
+importing/using it without that library (or without an MI355X) raises.
+"""
+from __future__ import annotations
+
+import weakref
+from dataclasses import dataclass, field, fields
+from typing import Optional
+
+import numpy as np
+
+from . import capi
+from .capi import (Context, VbmfError, VBMF_Y_F32, VBMF_Y_BF16, VBMF_FACTOR_AUTO, VBMF_FACTOR_BF16,
+                   VBMF_FACTOR_BF16X2, STEP_A, STEP_B, STEP_CA, STEP_CB, STEP_SIGMA2)
+
+__all__ = ["vbmf_parameters", "vbmf_init", "vbmf", "vbmf_", "copy", "updateA_", "updateB_", "updateCA_",
+           "updateCB_", "updateSigma2_", "updateYHat_", "elbo", "Session", "set_defaults", "capi"]
+
+# YHat (L x M float64) is materialised eagerly by the reference (src/vbmf.jl:70,217); above this many
+# elements the field is left None and computed on demand with updateYHat_ (8 GB at 100k x 10k).
+YHAT_AUTO_LIMIT = 1 << 24
+
+_defaults = dict(y_dtype=VBMF_Y_BF16, factor_dtype=VBMF_FACTOR_AUTO, device=0)
+
+
+def set_defaults(**kw):
+    """Device storage of Y / MFMA operand precision used by the reference-style functions."""
+    for k in kw:
+        if k not in _defaults:
+            raise KeyError(k)
+    _defaults.update(kw)
+
+
+@dataclass
+class vbmf_parameters:
+    """src/vbmf.jl:22-40 -- same field names, order and meaning."""
+    L: int = 0
+    M: int = 0
+    H: int = 0
+    H1: int = 0
+    labels: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=np.int64))   # 1-based, as in Julia
+    AHat: Optional[np.ndarray] = None
+    BHat: Optional[np.ndarray] = None
+    SigmaA: Optional[np.ndarray] = None
+    SigmaB: Optional[np.ndarray] = None
+    CA: Optional[np.ndarray] = None
+    CB: Optional[np.ndarray] = None
+    invCA: Optional[np.ndarray] = None
+    invCB: Optional[np.ndarray] = None
+    sigma2: float = 1.0
+    YHat: Optional[np.ndarray] = None
+
+
+def copy(params_in):
+    """src/vbmf.jl:80-88 -- shallow: the new struct shares every array with params_in."""
+    p = vbmf_parameters()
+    for f in fields(params_in):
+        setattr(p, f.name, getattr(params_in, f.name))
+    return p
+
+
+def _labels0(p):
+    lab = np.asarray(p.labels, dtype=np.int64)
+    if lab.size and (lab.min() < 1 or lab.max() > p.M):
+        raise IndexError("labels must be 1-based row indices of AHat (as in the reference)")
+    return lab - 1
+
+
+def vbmf_init(Y, H, ca=1.0, cb=1.0, sigma2=1.0, H1=0, labels=(), rng=None, materialize_yhat=None):
+    """src/vbmf.jl:48-73.  Host-side (the random draw is outside the hot path); `rng` is a
+    numpy Generator standing in for Julia's global RNG."""
+    Y = np.asarray(Y)
+    if Y.ndim != 2:
+        raise ValueError("Y must be a matrix")
+    rng = np.random.default_rng() if rng is None else rng
+    p = vbmf_parameters()
+    L, M = Y.shape
+    p.L, p.M, p.H, p.H1 = L, M, int(H), int(H1)
+    p.labels = np.asarray(labels, dtype=np.int64)
+    p.AHat = rng.standard_normal((M, H))
+    if p.H1 > 0 and p.labels.size:
+        p.AHat[_labels0(p), H - p.H1:] = 0.0                  # :61
+    p.BHat = rng.standard_normal((L, H))
+    p.SigmaA = np.zeros((H, H))
+    p.SigmaB = np.zeros((H, H))
+    p.CA = ca * np.eye(H)
+    p.CB = cb * np.eye(H)
+    p.invCA = np.eye(H) / ca
+    p.invCB = np.eye(H) / cb
+    p.sigma2 = float(sigma2)
+    if materialize_yhat is None:
+        materialize_yhat = L * M <= YHAT_AUTO_LIMIT
+    p.YHat = p.BHat @ p.AHat.T if materialize_yhat else None  # :70 (host: initialisation only)
+    return p
+
+
+class Session:
+    """Device-resident problem: Y uploaded (or generated) once, state kept on the GPU between calls.
+
+    The reference-style functions below are thin shells over a cached Session; use a Session
+    directly to avoid the state round trip per call at large sizes."""
+
+    def __init__(self, L, M, H, **ctx_kw):
+        kw = dict(_defaults)
+        kw.update(ctx_kw)
+        self.ctx = Context(L, M, H, **kw)
+        self.L, self.M, self.H = L, M, H
+
+    # -- data --
+    def set_Y(self, Y):
+        self.ctx.set_Y(Y)
+
+    def set_Y_synthetic(self, seed, Hstar, noise_std):
+        self.ctx.set_Y_synthetic(seed, Hstar, noise_std)
+
+    # -- state <-> vbmf_parameters --
+    def push(self, p):
+        ca, cb = np.diag(p.CA).copy(), np.diag(p.CB).copy()
+        self.ctx.set_state(p.AHat, p.BHat, p.SigmaA, p.SigmaB, ca, cb, p.sigma2, labels0=_labels0(p), H1=p.H1)
+
+    def pull(self, p, want_B=True):
+        """Rebind fields with fresh arrays (the reference's updates rebind, src/vbmf.jl:96-98,110-112);
+        CA/CB diagonals are written in place (src/vbmf.jl:131,143)."""
+        s = self.ctx.get_state(want_B=want_B)
+        p.AHat = s["AHat"]
+        if want_B:
+            p.BHat = s["BHat"]
+        p.SigmaA, p.SigmaB = s["SigmaA"], s["SigmaB"]
+        idx = np.arange(p.H)
+        p.CA[idx, idx] = s["CA_diag"]
+        p.CB[idx, idx] = s["CB_diag"]
+        p.invCA = np.diag(1.0 / s["CA_diag"])
+        p.invCB = np.diag(1.0 / s["CB_diag"])
+        p.sigma2 = s["sigma2"]
+        return p
+
+    def step(self, which):
+        self.ctx.step(which)
+
+    def run(self, niter, eps=1e-6, est_covs=False, est_var=False, want_trace=False):
+        return self.ctx.run(niter, eps=eps, est_covs=est_covs, est_var=est_var, want_trace=want_trace)
+
+    def close(self):
+        self.ctx.close()
+
+
+# ---- cached sessions keyed on the caller's Y array ------------------------------------------------
+_sessions = {}
+
+
+def _session_for(Y, H):
+    Y = np.asarray(Y, dtype=np.float64)
+    if Y.ndim != 2:
+        raise ValueError("Y must be a matrix")
+    key = (id(Y), Y.shape, Y.__array_interface__["data"][0], int(H), tuple(sorted(_defaults.items())))
+    ent = _sessions.get(key)
+    if ent is not None and ent[1]() is Y:
+        return ent[0]
+    for k in [k for k, v in _sessions.items() if v[1]() is None or k[:3] == key[:3]]:
+        _sessions.pop(k)[0].close()
+    s = Session(Y.shape[0], Y.shape[1], H)
+    s.set_Y(Y)
+    try:
+        ref = weakref.ref(Y)
+    except TypeError:
+        ref = (lambda y: (lambda: y))(Y)
+    _sessions[key] = (s, ref)
+    return s
+
+
+def _check(Y, p):
+    Y = np.asarray(Y)
+    if Y.shape != (p.L, p.M):
+        raise ValueError(f"Y is {Y.shape}, params describe {(p.L, p.M)}")
+
+
+def _one(Y, p, which, want_B):
+    _check(Y, p)
+    s = _session_for(Y, p.H)
+    s.push(p)
+    s.step(which)
+    s.pull(p, want_B=want_B)
+
+
+def updateA_(Y, params):
+    """updateA! -- src/vbmf.jl:95-102."""
+    _one(Y, params, STEP_A, False)
+
+
+def updateB_(Y, params):
+    """updateB! -- src/vbmf.jl:109-113."""
+    _one(Y, params, STEP_B, True)
+
+
+def updateCA_(params, Y=None):
+    """updateCA! -- src/vbmf.jl:129-134.  (Y only selects the cached device problem.)"""
+    if Y is None:
+        raise ValueError("updateCA_ needs the Y whose device session holds the problem")
+    _one(Y, params, STEP_CA, False)
+
+
+def updateCB_(params, Y=None):
+    """updateCB! -- src/vbmf.jl:141-146."""
+    if Y is None:
+        raise ValueError("updateCB_ needs the Y whose device session holds the problem")
+    _one(Y, params, STEP_CB, False)
+
+
+def updateSigma2_(Y, params):
+    """updateSigma2! -- src/vbmf.jl:153-157."""
+    _one(Y, params, STEP_SIGMA2, False)
+
+
+def updateYHat_(params, Y=None):
+    """updateYHat! -- src/vbmf.jl:120-122 (device GEMM, fp64 out)."""
+    if Y is None:
+        raise ValueError("updateYHat_ needs the Y whose device session holds the problem")
+    s = _session_for(Y, params.H)
+    s.push(params)
+    params.YHat = s.ctx.YHat()
+
+
+def elbo(Y, params):
+    """Build-defined ELBO of the basic model (the reference has none)."""
+    _check(Y, params)
+    s = _session_for(Y, params.H)
+    s.push(params)
+    return s.ctx.elbo()
+
+
+def vbmf_(Y, params, niter, eps=1e-6, est_covs=False, est_var=False, logdir="", desc="", verb=False):
+    """vbmf! -- src/vbmf.jl:175-231.  `params` is modified in place and returned."""
+    if logdir != "":
+        raise NotImplementedError("per-iteration JLD logging (src/data_manip.jl) is outside the accelerated path")
+    _check(Y, params)
+    s = _session_for(Y, params.H)
+    s.push(params)
+    iters, d, _ = s.run(int(niter), eps=eps, est_covs=est_covs, est_var=est_var)
+    s.pull(params)
+    if params.L * params.M <= YHAT_AUTO_LIMIT:
+        params.YHat = s.ctx.YHat()                             # :217
+    else:
+        params.YHat = None
+    if verb:
+        print(f"Factorization finished after {iters} iterations, eps = {d}")   # :221
+    params._last_run = (iters, d)
+    return params
+
+
+def vbmf(Y, params_in, niter, **kw):
+    """vbmf -- src/vbmf.jl:238-248: shallow-copies params_in, then vbmf!."""
+    p = copy(params_in)
+    # the reference's shallow copy would let updateCA!/updateCB! write into params_in.CA/CB
+    # (SURVEY App. A Q2); keep params_in reusable as the docstring at :235 promises
+    p.CA, p.CB = p.CA.copy(), p.CB.copy()
+    return vbmf_(Y, p, niter, **kw)

@@ -1,0 +1,227 @@
+"""ctypes binding of include/vbmf_hip.h -- the same entry points a Julia `ccall` binds.
+
+The library is loaded from this directory only (built in-tree by build.py).  If it is missing the
+import fails loudly: there is no CPU fallback and no alternate backend.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvbmf_hip.so")
+
+VBMF_Y_F32, VBMF_Y_BF16 = 0, 1
+VBMF_FACTOR_AUTO, VBMF_FACTOR_BF16, VBMF_FACTOR_BF16X2 = 0, 1, 2
+VBMF_VARIANT_BASIC, VBMF_VARIANT_SPARSE_DIAG = 0, 1
+VBMF_COMPAT_SPECTRAL_DELTA, VBMF_COMPAT_SPARSE_REPEAT, VBMF_COMPAT_DEFAULT = 1, 2, 0xFFFFFFFF
+STEP_A, STEP_B, STEP_CA, STEP_CB, STEP_SIGMA2 = 1, 2, 4, 8, 16
+UNIQUE_ID_BYTES = 128
+
+# every symbol include/vbmf_hip.h declares (checked by tests/test_capi_symbols.py)
+SYMBOLS = [
+    "vbmf_default_opts", "vbmf_create", "vbmf_destroy", "vbmf_last_error", "vbmf_set_Y", "vbmf_set_Y_synthetic",
+    "vbmf_get_Y", "vbmf_get_trYY", "vbmf_set_state", "vbmf_get_state", "vbmf_step", "vbmf_run", "vbmf_get_YHat",
+    "vbmf_elbo", "vbmf_comm_unique_id", "vbmf_comm_init", "vbmf_profile_enable", "vbmf_profile_read",
+    "vbmf_pass_bytes", "vbmf_device_sync",
+]
+
+
+class VbmfOpts(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32), ("device", C.c_int32), ("y_dtype", C.c_int32), ("factor_dtype", C.c_int32),
+        ("variant", C.c_int32), ("reference_compat", C.c_uint32), ("nranks", C.c_int32), ("rank", C.c_int32),
+        ("L_global", C.c_int64), ("row_offset", C.c_int64), ("pass1_splits", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class VbmfError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"vbmf_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Load libvbmf_hip.so (once).  Raises if the HIP library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python vbmatrixfactorization.jl_amd/build.py` "
+            "(hipcc, gfx950).  This package has no CPU fallback.")
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    dp, i64, i32, vp = C.POINTER(C.c_double), C.c_int64, C.c_int, C.c_void_p
+    L.vbmf_default_opts.argtypes = [C.POINTER(VbmfOpts)]
+    L.vbmf_default_opts.restype = None
+    L.vbmf_create.argtypes = [C.POINTER(vp), i64, i64, i64, C.POINTER(VbmfOpts)]
+    L.vbmf_destroy.argtypes = [vp]
+    L.vbmf_last_error.argtypes = [vp]
+    L.vbmf_last_error.restype = C.c_char_p
+    L.vbmf_set_Y.argtypes = [vp, dp, i64]
+    L.vbmf_set_Y_synthetic.argtypes = [vp, C.c_uint64, i64, C.c_double]
+    L.vbmf_get_Y.argtypes = [vp, dp, i64, i64, i64]
+    L.vbmf_get_trYY.argtypes = [vp, dp]
+    L.vbmf_set_state.argtypes = [vp, dp, i64, dp, i64, dp, dp, dp, dp, C.c_double, C.POINTER(i64), i64, i64]
+    L.vbmf_get_state.argtypes = [vp, dp, i64, dp, i64, dp, dp, dp, dp, dp]
+    L.vbmf_step.argtypes = [vp, i32]
+    L.vbmf_run.argtypes = [vp, i64, C.c_double, i32, i32, C.POINTER(i64), dp, dp]
+    L.vbmf_get_YHat.argtypes = [vp, dp, i64]
+    L.vbmf_elbo.argtypes = [vp, dp]
+    L.vbmf_comm_unique_id.argtypes = [vp]
+    L.vbmf_comm_init.argtypes = [vp, vp]
+    L.vbmf_profile_enable.argtypes = [vp, i32]
+    L.vbmf_profile_read.argtypes = [vp, dp, i32]
+    L.vbmf_pass_bytes.argtypes = [vp, i32, dp]
+    L.vbmf_device_sync.argtypes = [vp]
+    for name in SYMBOLS:
+        if name not in ("vbmf_default_opts", "vbmf_last_error"):
+            getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+def _dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+def _fcol(a, shape=None):
+    """float64, column-major (Julia Array{Float64,2} memory)."""
+    a = np.asarray(a, dtype=np.float64)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError(f"expected shape {shape}, got {a.shape}")
+    return np.asfortranarray(a)
+
+
+class Context:
+    """One problem on one GPU: thin, explicit wrapper over the C ABI (no numerics on the host)."""
+
+    def __init__(self, L, M, H, y_dtype=VBMF_Y_BF16, factor_dtype=VBMF_FACTOR_AUTO, device=0, nranks=1, rank=0,
+                 L_global=0, row_offset=0, reference_compat=VBMF_COMPAT_DEFAULT, pass1_splits=0):
+        self._lib = lib()
+        o = VbmfOpts()
+        self._lib.vbmf_default_opts(C.byref(o))
+        o.device, o.y_dtype, o.factor_dtype = device, y_dtype, factor_dtype
+        o.nranks, o.rank, o.L_global, o.row_offset = nranks, rank, L_global, row_offset
+        o.reference_compat, o.pass1_splits = reference_compat, pass1_splits
+        self._h = C.c_void_p()
+        rc = self._lib.vbmf_create(C.byref(self._h), L, M, H, C.byref(o))
+        if rc != 0:
+            msg = self._lib.vbmf_last_error(None).decode()
+            self._h = C.c_void_p()
+            raise VbmfError(rc, msg)
+        self.L, self.M, self.H = int(L), int(M), int(H)
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise VbmfError(rc, self._lib.vbmf_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.vbmf_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- Y ----
+    def set_Y(self, Y):
+        Y = _fcol(Y, (self.L, self.M))
+        self._chk(self._lib.vbmf_set_Y(self._h, _dptr(Y), Y.shape[0]))
+
+    def set_Y_synthetic(self, seed, Hstar, noise_std):
+        self._chk(self._lib.vbmf_set_Y_synthetic(self._h, seed, Hstar, noise_std))
+
+    def get_Y(self, row0=0, nrows=None):
+        nrows = self.L - row0 if nrows is None else nrows
+        out = np.empty((nrows, self.M), dtype=np.float64, order="F")
+        self._chk(self._lib.vbmf_get_Y(self._h, _dptr(out), nrows, row0, nrows))
+        return out
+
+    def trYY(self):
+        v = C.c_double()
+        self._chk(self._lib.vbmf_get_trYY(self._h, C.byref(v)))
+        return v.value
+
+    # ---- state ----
+    def set_state(self, AHat, BHat, SigmaA, SigmaB, CA_diag, CB_diag, sigma2, labels0=(), H1=0):
+        A = _fcol(AHat, (self.M, self.H)); B = _fcol(BHat, (self.L, self.H))
+        SA = _fcol(SigmaA, (self.H, self.H)); SB = _fcol(SigmaB, (self.H, self.H))
+        ca = np.ascontiguousarray(CA_diag, dtype=np.float64); cb = np.ascontiguousarray(CB_diag, dtype=np.float64)
+        if ca.shape != (self.H,) or cb.shape != (self.H,):
+            raise ValueError("CA_diag/CB_diag must have length H")
+        lab = np.ascontiguousarray(labels0, dtype=np.int64)
+        self._chk(self._lib.vbmf_set_state(self._h, _dptr(A), self.M, _dptr(B), self.L, _dptr(SA), _dptr(SB), _dptr(ca),
+                                           _dptr(cb), float(sigma2), lab.ctypes.data_as(C.POINTER(C.c_int64)),
+                                           lab.size, int(H1)))
+
+    def get_state(self, want_B=True):
+        A = np.empty((self.M, self.H), order="F"); B = np.empty((self.L, self.H), order="F") if want_B else None
+        SA = np.empty((self.H, self.H), order="F"); SB = np.empty((self.H, self.H), order="F")
+        ca = np.empty(self.H); cb = np.empty(self.H); s2 = C.c_double()
+        self._chk(self._lib.vbmf_get_state(self._h, _dptr(A), self.M, _dptr(B), self.L, _dptr(SA), _dptr(SB), _dptr(ca),
+                                           _dptr(cb), C.byref(s2)))
+        return dict(AHat=A, BHat=B, SigmaA=SA, SigmaB=SB, CA_diag=ca, CB_diag=cb, sigma2=s2.value)
+
+    # ---- updates ----
+    def step(self, which):
+        self._chk(self._lib.vbmf_step(self._h, which))
+
+    def run(self, niter, eps=1e-6, est_covs=False, est_var=False, want_trace=False):
+        it = C.c_int64(); d = C.c_double()
+        tr = np.zeros((max(niter, 1), 4)) if want_trace else None
+        self._chk(self._lib.vbmf_run(self._h, niter, eps, int(est_covs), int(est_var), C.byref(it), C.byref(d),
+                                     _dptr(tr)))
+        return it.value, d.value, (tr[:it.value] if want_trace else None)
+
+    def YHat(self):
+        out = np.empty((self.L, self.M), order="F")
+        self._chk(self._lib.vbmf_get_YHat(self._h, _dptr(out), self.L))
+        return out
+
+    def elbo(self):
+        v = C.c_double()
+        self._chk(self._lib.vbmf_elbo(self._h, C.byref(v)))
+        return v.value
+
+    # ---- multi-GPU ----
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(UNIQUE_ID_BYTES)
+        rc = lib().vbmf_comm_unique_id(buf)
+        if rc != 0:
+            raise VbmfError(rc, "ncclGetUniqueId failed")
+        return bytes(buf.raw)
+
+    def comm_init(self, uid):
+        buf = C.create_string_buffer(bytes(uid), UNIQUE_ID_BYTES)
+        self._chk(self._lib.vbmf_comm_init(self._h, buf))
+
+    # ---- measurement ----
+    def profile_enable(self, on=True):
+        self._chk(self._lib.vbmf_profile_enable(self._h, int(on)))
+
+    def profile_read(self, reset=True):
+        out = np.zeros(8)
+        self._chk(self._lib.vbmf_profile_read(self._h, _dptr(out), int(reset)))
+        return dict(pass1_ms=out[0], pass1_n=int(out[1]), pass2_ms=out[2], pass2_n=int(out[3]))
+
+    def pass_bytes(self, p):
+        v = C.c_double()
+        self._chk(self._lib.vbmf_pass_bytes(self._h, p, C.byref(v)))
+        return v.value
+
+    def sync(self):
+        self._chk(self._lib.vbmf_device_sync(self._h))

@@ -1,0 +1,280 @@
+// ctrl_kernels.hpp -- the H x H "control" algebra of a sweep, fp64, one workgroup, LDS-resident.
+//
+//   ctrl_cov_kernel   SigmaA = sigma2*inv(B'B + L*SigmaB + sigma2*inv(CA))   src/vbmf.jl:96-97
+//                     SigmaB = sigma2*inv(A'A + M*SigmaA + sigma2*inv(CB))   src/vbmf.jl:110-111
+//                     (in-LDS Gauss-Jordan on the SPD matrix; log-determinant from the pivots)
+//   eig_kernel        lambda_max of the delta-Gram and of the B-Gram (cyclic Jacobi, parallel ordering):
+//                     Julia 0.5 `norm(::Matrix)` is the spectral norm (src/util.jl:27-29)
+//   ctrl_end_kernel   updateCA!/updateCB! (src/vbmf.jl:129-146), updateSigma2! (src/vbmf.jl:153-157),
+//                     d (src/vbmf.jl:211), loop test (src/vbmf.jl:193), build-defined ELBO, trace record.
+//
+// fp64 because ARD drives entries of C toward 0 and precisions to 1e10; on a
+// 64..128-wide matrix the cost is negligible next to the streaming passes.
+#pragma once
+#include "common.hpp"
+
+namespace vbmf {
+
+// ---- layout of the device state block (doubles) ------------------------------------------------
+struct StateLayout {
+    int Hp;
+    __host__ __device__ long long n2() const { return (long long)Hp * Hp; }
+    __host__ __device__ long long GA() const { return 0; }
+    __host__ __device__ long long GB() const { return n2(); }
+    __host__ __device__ long long GD() const { return 2 * n2(); }     // must follow GB (one all-reduce)
+    __host__ __device__ long long SA() const { return 3 * n2(); }
+    __host__ __device__ long long SB() const { return 4 * n2(); }
+    __host__ __device__ long long KB() const { return 5 * n2(); }     // matrix inverted for SigmaB
+    __host__ __device__ long long W0() const { return 6 * n2(); }     // scratch (H > 128)
+    __host__ __device__ long long W1() const { return 7 * n2(); }
+    __host__ __device__ long long ca() const { return 8 * n2(); }
+    __host__ __device__ long long cb() const { return 8 * n2() + Hp; }
+    __host__ __device__ long long scal() const { return 8 * n2() + 2 * Hp; }
+    __host__ __device__ long long total() const { return scal() + 32; }
+};
+enum : int { S_SIGMA2 = 0, S_TRYY, S_LOGDET_SA, S_LOGDET_SB, S_LAMB_PREV, S_LAMB_NEW, S_LAMD, S_D, S_ELBO,
+             S_TRDOT, S_RESID, S_TRYBA };
+enum : int { I_STOP = 0, I_ITERS = 1, I_ERR = 2, I_NITER = 3 };
+
+__device__ __forceinline__ double block_sum(double v, double* red) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    const int nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int i = 0; i < nw; ++i) s += red[i];
+    return s;
+}
+__device__ __forceinline__ double block_max(double v, double* red) {
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off));
+    const int nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = red[0];
+    for (int i = 1; i < nw; ++i) s = fmax(s, red[i]);
+    return s;
+}
+
+// In-place inverse of the SPD n x n matrix W (leading dim n) by Gauss-Jordan without pivoting.
+// aux: 2n doubles.  Returns log det(W) (all threads).  Sets *err on a non-positive / non-finite pivot.
+__device__ inline double gj_inverse_spd(double* W, int n, double* aux, int* err) {
+    double* colk = aux;
+    double* rowk = aux + n;
+    double logdet = 0.0;
+    for (int k = 0; k < n; ++k) {
+        const double piv = W[(long long)k * n + k];
+        if (!(piv > 0.0) || !isfinite(piv)) { if (threadIdx.x == 0) atomicExch(err, 1); }
+        const double pinv = 1.0 / piv;
+        logdet += log(piv);
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            colk[i] = W[(long long)i * n + k];
+            rowk[i] = (i == k ? 1.0 : W[(long long)k * n + i]) * pinv;
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < n * n; t += blockDim.x) {
+            const int i = t / n, j = t - i * n;
+            double v;
+            if (i == k) v = rowk[j];
+            else v = (j == k ? 0.0 : W[t]) - colk[i] * rowk[j];
+            W[t] = v;
+        }
+        __syncthreads();
+    }
+    return logdet;
+}
+
+// which = 0: SigmaA from (GB, SigmaB, ca), N = L_global.  which = 1: SigmaB from (GA, SigmaA, cb), N = M.
+__global__ void ctrl_cov_kernel(double* __restrict__ st, StateLayout lay, int H, int which, double N,
+                                float* __restrict__ S32, int* __restrict__ ints, int use_lds) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    if (ints[I_STOP]) return;
+    const int Hp = lay.Hp;
+    double* W = use_lds ? lds : (st + lay.W0());
+    double* aux = use_lds ? (lds + (long long)H * H) : (st + lay.W1());
+    const double* G = st + (which == 0 ? lay.GB() : lay.GA());
+    double* Sother = st + (which == 0 ? lay.SB() : lay.SA());
+    double* Sself = st + (which == 0 ? lay.SA() : lay.SB());
+    const double* cdiag = st + (which == 0 ? lay.ca() : lay.cb());
+    double* scal = st + lay.scal();
+    const double sigma2 = scal[S_SIGMA2];
+    for (int t = threadIdx.x; t < H * H; t += blockDim.x) {
+        const int i = t / H, j = t - i * H;
+        double v = G[(long long)i * Hp + j] + N * Sother[(long long)i * Hp + j];
+        if (i == j) v += sigma2 / cdiag[i];
+        W[t] = v;
+        if (which == 1) st[lay.KB() + (long long)i * Hp + j] = v;
+    }
+    __syncthreads();
+    const double logdetK = gj_inverse_spd(W, H, aux, ints + I_ERR);
+    for (int t = threadIdx.x; t < Hp * Hp; t += blockDim.x) {
+        const int i = t / Hp, j = t - i * Hp;
+        const double w = (i < H && j < H) ? W[(long long)i * H + j] : 0.0;
+        Sself[t] = sigma2 * w;
+        S32[t] = (float)w;                      // Sigma/sigma2, the matrix the post kernel multiplies by
+    }
+    if (threadIdx.x == 0) scal[which == 0 ? S_LOGDET_SA : S_LOGDET_SB] = (double)H * log(sigma2) - logdetK;
+}
+
+// lambda_max of a symmetric PSD H x H matrix: block 0 -> GD (S_LAMD), block 1 -> GB (S_LAMB_NEW).
+// spectral = 0: Frobenius surrogate (trace) instead.
+__global__ void eig_kernel(double* __restrict__ st, StateLayout lay, int H, int spectral, int do_d, int do_b,
+                           const int* __restrict__ ints, int use_lds) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ double red[16];
+    if (ints[I_STOP]) return;
+    const int which = blockIdx.x;           // 0: GD, 1: GB
+    if ((which == 0 && !do_d) || (which == 1 && !do_b)) return;
+    const int Hp = lay.Hp;
+    const double* G = st + (which == 0 ? lay.GD() : lay.GB());
+    double* scal = st + lay.scal();
+    const int slot = which == 0 ? S_LAMD : S_LAMB_NEW;
+    if (!spectral) {
+        double tr = 0.0;
+        for (int i = threadIdx.x; i < H; i += blockDim.x) tr += G[(long long)i * Hp + i];
+        tr = block_sum(tr, red);
+        if (threadIdx.x == 0) scal[slot] = tr;
+        return;
+    }
+    const int n = (H + 1) & ~1;             // even size; an odd H gets a zero row/column (eigenvalue 0)
+    double* A = use_lds ? lds : (st + (which == 0 ? lay.W0() : lay.W1()));
+    double* cs = use_lds ? (lds + (long long)n * n) : nullptr;      // 2*(n/2) doubles
+    __shared__ double cs_small[2 * 128];
+    if (!use_lds) cs = cs_small;
+    for (int t = threadIdx.x; t < n * n; t += blockDim.x) {
+        const int i = t / n, j = t - i * n;
+        A[t] = (i < H && j < H) ? 0.5 * (G[(long long)i * Hp + j] + G[(long long)j * Hp + i]) : 0.0;
+    }
+    __syncthreads();
+    const int np = n / 2;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0.0, dg = 0.0;
+        for (int t = threadIdx.x; t < n * n; t += blockDim.x) {
+            const int i = t / n, j = t - i * n;
+            const double v = A[t];
+            if (i == j) dg += v * v; else off += v * v;
+        }
+        off = block_sum(off, red);
+        dg = block_sum(dg, red);
+        if (!(off > 1e-30 * dg)) break;     // uniform: every thread sees the same sums
+        for (int r = 0; r < n - 1; ++r) {
+            // round-robin tournament: position 0 fixed, the others rotate
+            for (int i = threadIdx.x; i < np; i += blockDim.x) {
+                const int a = i, b = n - 1 - i;
+                const int p0 = (a == 0) ? 0 : 1 + ((a - 1 + r) % (n - 1));
+                const int q0 = 1 + ((b - 1 + r) % (n - 1));
+                const int p = min(p0, q0), q = max(p0, q0);
+                const double apq = A[(long long)p * n + q];
+                double c = 1.0, s = 0.0;
+                if (apq != 0.0) {
+                    const double theta = (A[(long long)q * n + q] - A[(long long)p * n + p]) / (2.0 * apq);
+                    const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                    c = 1.0 / sqrt(t * t + 1.0);
+                    s = t * c;
+                }
+                cs[2 * i] = c;
+                cs[2 * i + 1] = s;
+            }
+            __syncthreads();
+            for (int t = threadIdx.x; t < np * n; t += blockDim.x) {      // rows: A <- J' A
+                const int i = t / n, j = t - i * n;
+                const int a = i, b = n - 1 - i;
+                const int p0 = (a == 0) ? 0 : 1 + ((a - 1 + r) % (n - 1));
+                const int q0 = 1 + ((b - 1 + r) % (n - 1));
+                const int p = min(p0, q0), q = max(p0, q0);
+                const double c = cs[2 * i], s = cs[2 * i + 1];
+                const double x = A[(long long)p * n + j], y = A[(long long)q * n + j];
+                A[(long long)p * n + j] = c * x - s * y;
+                A[(long long)q * n + j] = s * x + c * y;
+            }
+            __syncthreads();
+            for (int t = threadIdx.x; t < np * n; t += blockDim.x) {      // columns: A <- A J
+                const int i = t / n, j = t - i * n;
+                const int a = i, b = n - 1 - i;
+                const int p0 = (a == 0) ? 0 : 1 + ((a - 1 + r) % (n - 1));
+                const int q0 = 1 + ((b - 1 + r) % (n - 1));
+                const int p = min(p0, q0), q = max(p0, q0);
+                const double c = cs[2 * i], s = cs[2 * i + 1];
+                const double x = A[(long long)j * n + p], y = A[(long long)j * n + q];
+                A[(long long)j * n + p] = c * x - s * y;
+                A[(long long)j * n + q] = s * x + c * y;
+            }
+            __syncthreads();
+        }
+    }
+    double mx = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) mx = fmax(mx, A[(long long)i * n + i]);
+    mx = block_max(mx, red);
+    if (threadIdx.x == 0) scal[slot] = mx;
+}
+
+// flags: bit0 est_covs->CA, bit1 est_covs->CB, bit2 est_var, bit3 compute d + loop bookkeeping,
+//        bit4 tr(Y'BA') from the Gram identity tr(KB o GB) (else from scal[S_TRDOT])
+__global__ __launch_bounds__(256) void ctrl_end_kernel(double* __restrict__ st, StateLayout lay, int H, double Lg,
+                                                       double M, int flags, double eps,
+                                                       double* __restrict__ trace, int* __restrict__ ints) {
+    __shared__ double red[16];
+    if (ints[I_STOP]) return;
+    const int Hp = lay.Hp;
+    const double* GA = st + lay.GA();
+    const double* GB = st + lay.GB();
+    const double* SA = st + lay.SA();
+    const double* SB = st + lay.SB();
+    const double* KB = st + lay.KB();
+    double* ca = st + lay.ca();
+    double* cb = st + lay.cb();
+    double* scal = st + lay.scal();
+
+    // tr(Y'BA') and tr((A'A + M SigmaA)(B'B + L SigmaB))
+    double t1 = 0.0, t2 = 0.0;
+    for (int t = threadIdx.x; t < H * H; t += blockDim.x) {
+        const int i = t / H, j = t - i * H;
+        const long long ij = (long long)i * Hp + j;
+        t1 += KB[ij] * GB[ij];
+        t2 += (GA[ij] + M * SA[ij]) * (GB[ij] + Lg * SB[ij]);
+    }
+    t1 = block_sum(t1, red);
+    t2 = block_sum(t2, red);
+    const double trYBA = (flags & 16) ? t1 : scal[S_TRDOT];
+    const double resid = scal[S_TRYY] - 2.0 * trYBA + t2;
+    __syncthreads();
+    if (flags & 1) for (int h = threadIdx.x; h < H; h += blockDim.x) ca[h] = GA[(long long)h * Hp + h] / M + SA[(long long)h * Hp + h];
+    if (flags & 2) for (int h = threadIdx.x; h < H; h += blockDim.x) cb[h] = GB[(long long)h * Hp + h] / Lg + SB[(long long)h * Hp + h];
+    __syncthreads();
+    double sigma2 = scal[S_SIGMA2];
+    if (flags & 4) sigma2 = resid / (Lg * M);
+
+    // build-defined ELBO, with the post-update CA, CB, sigma2
+    double e = 0.0;
+    for (int h = threadIdx.x; h < H; h += blockDim.x) {
+        const long long hh = (long long)h * Hp + h;
+        e += -(M / 2.0) * log(ca[h]) - 0.5 * (GA[hh] + M * SA[hh]) / ca[h];
+        e += -(Lg / 2.0) * log(cb[h]) - 0.5 * (GB[hh] + Lg * SB[hh]) / cb[h];
+    }
+    e = block_sum(e, red);
+    if (threadIdx.x == 0) {
+        const double PI2 = 6.283185307179586476925286766559;
+        double F = -(Lg * M / 2.0) * log(PI2 * sigma2) - resid / (2.0 * sigma2) + e;
+        F += (M / 2.0) * scal[S_LOGDET_SA] + M * H / 2.0 + (Lg / 2.0) * scal[S_LOGDET_SB] + Lg * H / 2.0;
+        scal[S_SIGMA2] = sigma2;
+        scal[S_ELBO] = F;
+        scal[S_RESID] = resid;
+        scal[S_TRYBA] = trYBA;
+        if (flags & 8) {
+            const double d = sqrt(scal[S_LAMD] / scal[S_LAMB_PREV]);
+            scal[S_D] = d;
+            scal[S_LAMB_PREV] = scal[S_LAMB_NEW];
+            const int it = ints[I_ITERS];
+            if (trace) { trace[4 * it + 0] = d; trace[4 * it + 1] = sigma2; trace[4 * it + 2] = F; trace[4 * it + 3] = resid; }
+            ints[I_ITERS] = it + 1;
+            if (!(d > eps) || it + 1 >= ints[I_NITER]) ints[I_STOP] = 1;    // src/vbmf.jl:193 (NaN d exits too)
+        }
+    }
+}
+
+__global__ void copy_scalar_kernel(double* st, StateLayout lay, int dst, int src) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) st[lay.scal() + dst] = st[lay.scal() + src];
+}
+
+}  // namespace vbmf

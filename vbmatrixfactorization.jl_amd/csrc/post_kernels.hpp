@@ -1,0 +1,265 @@
+// post_kernels.hpp -- everything between the two streaming passes that touches M x H or L x H data.
+//
+//   post_kernel     Fac[x][h'] = sum_h (sum_s In[s][h][x]) * S[h][h']   (AHat = (Y'B) SigmaA/sigma2,
+//                   src/vbmf.jl:98; BHat = (Y A) SigmaB/sigma2, src/vbmf.jl:112), label mask
+//                   (src/vbmf.jl:101), fp32 row-major store, and the bf16(-hi/lo)/f32 MFMA operand
+//                   tiles the NEXT streaming pass consumes.  Exact-f32 MFMA (v_mfma_f32_32x32x2_f32).
+//   retile_kernel   operand tiles from an fp32 row-major factor (vbmf_set_state).
+//   gram_kernel     G = Fac'Fac and, given the previous factor, D = (Prev-Fac)'(Prev-Fac) -- the
+//                   difference is formed element-wise BEFORE squaring (src/util.jl:27-29 needs
+//                   ||B_old - B_new|| near convergence where Gram differences would cancel).
+//                   Accumulator tiles are fed back as both MFMA operands (sum over the row index
+//                   that lives in registers), so no transpose is needed.
+//   reduce kernels  fp64 reduction of per-chunk Gram slabs; fp32 sum of split-K slabs.
+//   dot_kernel      sum_{x,h} In[h][x]*Fac[x][h]  (tr(Y'BA') when the Gram identity is unavailable).
+#pragma once
+#include "common.hpp"
+
+namespace vbmf {
+
+// ---- emit the operand tiles of one 32-row accumulator tile (rows = k of the next pass) ----------
+template <int MODE, int NH>
+__device__ __forceinline__ void write_factor_tiles(uint4* __restrict__ Ft, const f32x16& v, int xt, int nh,
+                                                   int lane) {
+    constexpr int NPART = ModeTraits<MODE>::NPART;
+    if constexpr (MODE == MODE_F32) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {                      // k-step (8 rows) 4*xt+g, element e = r&3
+            uint4 o;
+            o.x = __builtin_bit_cast(unsigned, v[4 * g + 0]); o.y = __builtin_bit_cast(unsigned, v[4 * g + 1]);
+            o.z = __builtin_bit_cast(unsigned, v[4 * g + 2]); o.w = __builtin_bit_cast(unsigned, v[4 * g + 3]);
+            Ft[((long long)(4 * xt + g) * NH + nh) * 64 + lane] = o;
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {                      // k-step (16 rows) 2*xt+s, element e = r&7
+            unsigned short hi[8], lo[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = v[8 * s + e];
+                hi[e] = f2bf(f);
+                lo[e] = f2bf(f - bf2f(hi[e]));
+            }
+            uint4 o;
+            o.x = hi[0] | ((unsigned)hi[1] << 16); o.y = hi[2] | ((unsigned)hi[3] << 16);
+            o.z = hi[4] | ((unsigned)hi[5] << 16); o.w = hi[6] | ((unsigned)hi[7] << 16);
+            const long long base = (long long)(2 * xt + s) * NPART;
+            Ft[((base + 0) * NH + nh) * 64 + lane] = o;
+            if constexpr (NPART == 2) {
+                o.x = lo[0] | ((unsigned)lo[1] << 16); o.y = lo[2] | ((unsigned)lo[3] << 16);
+                o.z = lo[4] | ((unsigned)lo[5] << 16); o.w = lo[6] | ((unsigned)lo[7] << 16);
+                Ft[((base + 1) * NH + nh) * 64 + lane] = o;
+            }
+        }
+    }
+}
+
+// One wave per 32-row tile of the factor.  In: [nslab][Hp][ldIn] fp32 (x fastest), S: [Hp][Hp] fp32
+// row-major, Fac: [XT*32][Hp] fp32 row-major.
+template <int MODE, int NH>
+__global__ __launch_bounds__(256) void post_kernel(const float* __restrict__ In, long long ldIn, int nslab,
+                                                   long long slabStride, const float* __restrict__ S,
+                                                   float* __restrict__ Fac, uint4* __restrict__ Ft,
+                                                   const unsigned char* __restrict__ mask, int hmask_start, int XT,
+                                                   const int* __restrict__ stop) {
+    constexpr int Hp = NH * 32;
+    if (stop && *stop) return;
+    const int lane = threadIdx.x & 63;
+    const int xt = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (xt >= XT) return;
+    const int c = lane & 31, half = lane >> 5;
+    const long long x0 = (long long)xt * 32;
+
+    f32x16 acc[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[h][r] = 0.f;
+
+    for (int hin = 0; hin < NH; ++hin) {
+#pragma unroll 4
+        for (int t = 0; t < 16; ++t) {
+            const int hk = hin * 32 + 2 * t + half;               // contraction index of this lane-half
+            const float* ip = In + (long long)hk * ldIn + x0 + c;
+            float a = 0.f;
+            for (int s = 0; s < nslab; ++s) a += ip[(long long)s * slabStride];
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                const float b = S[(long long)hk * Hp + h * 32 + c];
+                acc[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[h], 0, 0, 0);
+            }
+        }
+    }
+
+    // accumulator layout: lane (c = h' in tile, half), register r -> row x0 + rho(r, half)
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        const int hcol = h * 32 + c;
+        if (mask != nullptr && hcol >= hmask_start) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (mask[x0 + rho(r, half)]) acc[h][r] = 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Fac[(x0 + rho(r, half)) * Hp + hcol] = acc[h][r];
+        write_factor_tiles<MODE, NH>(Ft, acc[h], xt, h, lane);
+    }
+}
+
+template <int MODE, int NH>
+__global__ __launch_bounds__(256) void retile_kernel(const float* __restrict__ Fac, uint4* __restrict__ Ft, int XT) {
+    constexpr int Hp = NH * 32;
+    const int lane = threadIdx.x & 63;
+    const int xt = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (xt >= XT) return;
+    const int c = lane & 31, half = lane >> 5;
+    const long long x0 = (long long)xt * 32;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        f32x16 v;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = Fac[(x0 + rho(r, half)) * Hp + h * 32 + c];
+        write_factor_tiles<MODE, NH>(Ft, v, xt, h, lane);
+    }
+}
+
+// One wave per (chunk of 32-row tiles, ordered tile pair (h1,h2)).  slabs: [nchunk][2][Hp][Hp] fp32.
+template <int NH>
+__global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ Cur, const float* __restrict__ Prev,
+                                                   float* __restrict__ slabs, int XT, int tiles_per_chunk,
+                                                   int nchunk, const int* __restrict__ stop) {
+    constexpr int Hp = NH * 32;
+    if (stop && *stop) return;
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= nchunk * NH * NH) return;
+    const int chunk = w / (NH * NH), pair = w % (NH * NH);
+    const int h1 = pair / NH, h2 = pair % NH;
+    const int c = lane & 31, half = lane >> 5;
+    f32x16 g, d;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { g[r] = 0.f; d[r] = 0.f; }
+    const int t0 = chunk * tiles_per_chunk;
+    const int t1 = min(XT, t0 + tiles_per_chunk);
+    for (int xt = t0; xt < t1; ++xt) {
+        const long long x0 = (long long)xt * 32;
+        float a1[16], a2[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long long row = (x0 + rho(r, half)) * Hp;
+            a1[r] = Cur[row + h1 * 32 + c];
+            a2[r] = Cur[row + h2 * 32 + c];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[r], a2[r], g, 0, 0, 0);
+        if (Prev != nullptr) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long row = (x0 + rho(r, half)) * Hp;
+                a1[r] = Prev[row + h1 * 32 + c] - a1[r];
+                a2[r] = Prev[row + h2 * 32 + c] - a2[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[r], a2[r], d, 0, 0, 0);
+        }
+    }
+    float* o = slabs + (long long)chunk * 2 * Hp * Hp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const long long idx = (long long)(h1 * 32 + rho(r, half)) * Hp + h2 * 32 + c;
+        o[idx] = g[r];
+        o[(long long)Hp * Hp + idx] = d[r];
+    }
+}
+
+// out[which][i] = sum_chunk slabs[chunk][which][i]  (fp64).  which in {0: Gram, 1: delta-Gram}.
+__global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restrict__ slabs, int nchunk, int n,
+                                                          double* __restrict__ outG, double* __restrict__ outD,
+                                                          const int* __restrict__ stop) {
+    if (stop && *stop) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * n) return;
+    const int which = i / n, j = i % n;
+    double* out = which ? outD : outG;
+    if (out == nullptr) return;
+    double s = 0.0;
+    for (int ch = 0; ch < nchunk; ++ch) s += (double)slabs[((long long)ch * 2 + which) * n + j];
+    out[j] = s;
+}
+
+// out[i] = sum_s slabs[s][i]   (fp32, fixed order => deterministic)
+__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slabs, int nslab,
+                                                       long long slabStride, float* __restrict__ out, long long n,
+                                                       const int* __restrict__ stop) {
+    if (stop && *stop) return;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < nslab; ++k) s += slabs[(long long)k * slabStride + i];
+        out[i] = s;
+    }
+}
+
+// *out += sum_{x<X, h<Hp} (sum_s In[s][h][x]) * Fac[x][h]
+__global__ __launch_bounds__(256) void dot_kernel(const float* __restrict__ In, long long ldIn, int nslab,
+                                                  long long slabStride, const float* __restrict__ Fac, int Hp,
+                                                  long long X, double* __restrict__ out) {
+    double acc = 0.0;
+    for (long long x = (long long)blockIdx.x * blockDim.x + threadIdx.x; x < X;
+         x += (long long)gridDim.x * blockDim.x) {
+        for (int h = 0; h < Hp; ++h) {
+            float a = 0.f;
+            for (int s = 0; s < nslab; ++s) a += In[(long long)s * slabStride + (long long)h * ldIn + x];
+            acc += (double)a * (double)Fac[x * Hp + h];
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    __shared__ double part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+
+// dst[i] = src[i] unless the sweep loop has stopped (keeps the state frozen after `stop`)
+__global__ void gated_copy_kernel(const double* __restrict__ src, double* __restrict__ dst, int n,
+                                  const int* __restrict__ stop) {
+    if (stop && *stop) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+// fp64 column-major host layout <-> fp32 row-major padded device layout
+__global__ void pack_factor_kernel(const double* __restrict__ src, long long ld, long long X, int H, int Hp,
+                                   long long Xp, float* __restrict__ dst) {
+    const long long total = Xp * Hp;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long x = i / Hp; const int h = (int)(i % Hp);
+        dst[i] = (x < X && h < H) ? (float)src[x + (long long)h * ld] : 0.f;
+    }
+}
+__global__ void unpack_factor_kernel(const float* __restrict__ src, int Hp, long long X, int H,
+                                     double* __restrict__ dst, long long ld) {
+    const long long total = X * H;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long x = i % X; const int h = (int)(i / X);
+        dst[x + (long long)h * ld] = (double)src[x * Hp + h];
+    }
+}
+
+// YHat = BHat * AHat'  (src/vbmf.jl:120-122), fp32 factors, fp64 column-major out.  On demand only.
+__global__ __launch_bounds__(256) void yhat_kernel(const float* __restrict__ B, const float* __restrict__ A, int Hp,
+                                                   int H, long long L, long long M, double* __restrict__ out,
+                                                   long long ld) {
+    const long long total = L * M;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long l = i % L, m = i / L;
+        double s = 0.0;
+        for (int h = 0; h < H; ++h) s += (double)B[l * Hp + h] * (double)A[m * Hp + h];
+        out[l + m * ld] = s;
+    }
+}
+
+}  // namespace vbmf

@@ -1,0 +1,936 @@
+// vbmf_hip.hip -- context, sweep orchestration and the C ABI declared in include/vbmf_hip.h.
+//
+// One sweep of vbmf! (src/vbmf.jl:193-214) on the device:
+//
+//   ctrl_cov(A)   SigmaA                      H x H fp64, one workgroup          src/vbmf.jl:96-97
+//   stream pass 1 P[s] = Y' B   (split-K)     reads Y once (copy tiled for k=l)  src/vbmf.jl:98
+//   [slab_sum + RCCL all-reduce of P when Y is row-sharded]
+//   post(A)       AHat = P SigmaA/sigma2, label mask, fp32 store, operand tiles  src/vbmf.jl:98,101
+//   gram(A)       A'A -> fp64
+//   ctrl_cov(B)   SigmaB                                                         src/vbmf.jl:110-111
+//   stream pass 2 Q = Y A                     reads Y once (copy tiled for k=m)  src/vbmf.jl:112
+//   post(B)       BHat = Q SigmaB/sigma2, fp32 store, operand tiles              src/vbmf.jl:112
+//   gram(B)       B'B and (Bold-B)'(Bold-B) -> fp64 [+ RCCL all-reduce]
+//   eig           lambda_max of both (spectral norms of src/util.jl:27-29)
+//   ctrl_end      CA, CB, sigma2, d, loop test, ELBO, trace                      src/vbmf.jl:129-157,193,211
+//
+// Every kernel of a sweep starts with `if (*stop) return`, and ctrl_end raises `stop` exactly when
+// the reference's `while (i <= niter) && (d > eps)` would exit, so the host can enqueue sweeps ahead
+// without a per-sweep synchronisation and the state still freezes at the reference's iteration.
+#include "../../include/vbmf_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+#include "ctrl_kernels.hpp"
+#include "post_kernels.hpp"
+#include "rng.hpp"
+#include "stream_gemm.hpp"
+#include "tile_kernels.hpp"
+
+using namespace vbmf;
+
+static thread_local std::string g_create_error;
+
+struct ProfEvent { hipEvent_t a, b; int pass; };
+
+struct vbmf_ctx {
+    std::string err;
+    vbmf_opts o{};
+    int64_t L = 0, M = 0, H = 0, Lg = 0;
+    int Hp = 0, NH = 0, mode = 0, kstep = 16, npart = 1;
+    Dims d1{}, d2{};                 // pass 1: x=m,k=l ; pass 2: x=l,k=m
+    int64_t Mp = 0, Lp = 0;
+    uint4 *Y1 = nullptr, *Y2 = nullptr, *FA = nullptr, *FB = nullptr;
+    size_t nY1 = 0, nY2 = 0, nFA = 0, nFB = 0;
+    float *P = nullptr, *Q = nullptr, *Pred = nullptr;
+    float *A32 = nullptr, *B32[2] = {nullptr, nullptr};
+    int bcur = 0;
+    float *SA32 = nullptr, *SB32 = nullptr, *gslab = nullptr;
+    int tiles_per_chunk = 32;
+    double* st = nullptr;
+    double* gtmp = nullptr;          // 2*Hp^2 local Gram sums (all-reduce staging)
+    StateLayout lay{};
+    int* ints = nullptr;
+    int* ints_host = nullptr;        // pinned
+    double* scal_host = nullptr;     // pinned, 32 doubles
+    unsigned char* mask = nullptr;
+    int64_t H1 = 0;
+    bool has_mask = false;
+    hipStream_t stream = nullptr;
+    bool haveY = false, haveState = false;
+    bool gA_valid = false, gB_valid = false, P_valid = false, kb_identity = false;
+    double trYY_local = 0.0;
+    bool trYY_reduced = true;
+    bool prof = false;
+    std::vector<ProfEvent> pev;
+    double prof_ms[2] = {0, 0};
+    double prof_n[2] = {0, 0};
+    ncclComm_t comm = nullptr;
+    bool comm_ready = false;
+    int lds_limit = 65536;
+};
+
+// ------------------------------------------------------------------------------------------------
+#define FAIL(ctx, code, ...)                                   \
+    do {                                                       \
+        char _b[512];                                          \
+        snprintf(_b, sizeof _b, __VA_ARGS__);                  \
+        (ctx)->err = _b;                                       \
+        return (code);                                         \
+    } while (0)
+
+#define HIPCHK(ctx, call)                                                                              \
+    do {                                                                                               \
+        hipError_t _e = (call);                                                                        \
+        if (_e != hipSuccess) FAIL(ctx, VBMF_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), \
+                                   __FILE__, __LINE__);                                                \
+    } while (0)
+
+#define NCCLCHK(ctx, call)                                                                               \
+    do {                                                                                                 \
+        ncclResult_t _e = (call);                                                                        \
+        if (_e != ncclSuccess) FAIL(ctx, VBMF_ERR_COMM, "%s failed: %s (%s:%d)", #call, ncclGetErrorString(_e), \
+                                    __FILE__, __LINE__);                                                 \
+    } while (0)
+
+#define TRY(expr)                 \
+    do {                          \
+        int _rc = (expr);         \
+        if (_rc != VBMF_OK) return _rc; \
+    } while (0)
+
+#define DISPATCH_NH(nh, ...)                                   \
+    switch (nh) {                                              \
+        case 1: { constexpr int NHc = 1; __VA_ARGS__; } break; \
+        case 2: { constexpr int NHc = 2; __VA_ARGS__; } break; \
+        case 4: { constexpr int NHc = 4; __VA_ARGS__; } break; \
+        case 8: { constexpr int NHc = 8; __VA_ARGS__; } break; \
+        default: break;                                        \
+    }
+#define DISPATCH_MODE(md, ...)                                                     \
+    switch (md) {                                                                  \
+        case MODE_F32: { constexpr int MODEc = MODE_F32; __VA_ARGS__; } break;     \
+        case MODE_BF16: { constexpr int MODEc = MODE_BF16; __VA_ARGS__; } break;   \
+        case MODE_BF16X2: { constexpr int MODEc = MODE_BF16X2; __VA_ARGS__; } break; \
+        default: break;                                                            \
+    }
+
+static inline int64_t rup(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+static inline int grid_for(int64_t n, int block = 256, int cap = 8192) {
+    return (int)std::max<int64_t>(1, std::min<int64_t>((n + block - 1) / block, cap));
+}
+
+// per-NH geometry of the streaming kernel (register budget: acc = NXW*NH*16, ring = D*(NXW+NF)*4)
+template <int NH> struct StreamCfg { static constexpr int NXWc = 2; static constexpr int Dc = 4; };
+template <> struct StreamCfg<4> { static constexpr int NXWc = 2; static constexpr int Dc = 2; };
+template <> struct StreamCfg<8> { static constexpr int NXWc = 1; static constexpr int Dc = 2; };
+
+static int nxw_of(int NH) { return NH == 8 ? 1 : 2; }
+
+static void plan_pass(Dims& d, int64_t X, int64_t K, int kstep, int NH, int want_splits) {
+    d.XT = (int)rup(cdiv(X, 32), NXW);
+    const int64_t ks_min = rup(cdiv(rup(K, 32 * NXW), kstep), PIPE_D);   // K padded like the other pass's x tiles
+    const int XG = d.XT / nxw_of(NH);
+    int ns = want_splits;
+    if (ns <= 0) {                                                    // aim at ~2300 waves (9 per CU)
+        ns = (int)std::max<int64_t>(1, (2304 + XG / 2) / std::max(1, XG));
+        ns = std::min(ns, 64);
+    }
+    ns = (int)std::max<int64_t>(1, std::min<int64_t>(ns, ks_min / (2 * PIPE_D)));   // >= 8 steps per split
+    if (ns >= 8) ns = ns / 8 * 8;                                     // XCD-aware mapping wants % 8
+    d.nsplit = std::max(1, ns);
+    d.steps_per_split = (int)rup(cdiv(ks_min, d.nsplit), PIPE_D);
+    d.KS = d.steps_per_split * d.nsplit;
+}
+
+// ------------------------------------------------------------------------------------------------
+static void prof_begin(vbmf_ctx* c, int pass) {
+    if (!c->prof) return;
+    ProfEvent e{};
+    e.pass = pass;
+    hipEventCreate(&e.a);
+    hipEventCreate(&e.b);
+    hipEventRecord(e.a, c->stream);
+    c->pev.push_back(e);
+}
+static void prof_end(vbmf_ctx* c) {
+    if (!c->prof) return;
+    hipEventRecord(c->pev.back().b, c->stream);
+}
+static void prof_harvest(vbmf_ctx* c) {
+    for (auto& e : c->pev) {
+        hipEventSynchronize(e.b);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e.a, e.b);
+        c->prof_ms[e.pass] += ms;
+        c->prof_n[e.pass] += 1;
+        hipEventDestroy(e.a);
+        hipEventDestroy(e.b);
+    }
+    c->pev.clear();
+}
+
+static int launch_stream(vbmf_ctx* c, int pass) {
+    const Dims& d = pass == 0 ? c->d1 : c->d2;
+    const uint4* Y = pass == 0 ? c->Y1 : c->Y2;
+    const uint4* F = pass == 0 ? c->FB : c->FA;
+    float* out = pass == 0 ? c->P : c->Q;
+    const long long ld = (long long)d.XT * 32;
+    const int XG = d.XT / nxw_of(c->NH);
+    const int bps = (XG + 3) / 4;
+    const int grid = bps * d.nsplit;
+    prof_begin(c, pass);
+    DISPATCH_MODE(c->mode, DISPATCH_NH(c->NH, {
+        using Cfg = StreamCfg<NHc>;
+        hipLaunchKernelGGL((stream_gemm_kernel<MODEc, NHc, Cfg::NXWc, Cfg::Dc>), dim3(grid), dim3(256), 0, c->stream,
+                           Y, F, out, XG, d.KS, d.steps_per_split, d.nsplit, ld, c->ints + I_STOP);
+    }));
+    prof_end(c);
+    HIPCHK(c, hipGetLastError());
+    return VBMF_OK;
+}
+
+static int launch_post(vbmf_ctx* c, int which, const float* In, int nslab) {
+    const Dims& d = which == 0 ? c->d1 : c->d2;
+    const long long ld = (long long)d.XT * 32;
+    const long long slabStride = (long long)c->Hp * ld;
+    const float* S = which == 0 ? c->SA32 : c->SB32;
+    float* Fac = which == 0 ? c->A32 : c->B32[c->bcur ^ 1];
+    uint4* Ft = which == 0 ? c->FA : c->FB;
+    const unsigned char* mk = (which == 0 && c->has_mask) ? c->mask : nullptr;
+    const int hstart = (int)(c->H - c->H1);
+    const int grid = (d.XT + 3) / 4;
+    DISPATCH_MODE(c->mode, DISPATCH_NH(c->NH, {
+        hipLaunchKernelGGL((post_kernel<MODEc, NHc>), dim3(grid), dim3(256), 0, c->stream, In, ld, nslab, slabStride, S,
+                           Fac, Ft, mk, hstart, d.XT, c->ints + I_STOP);
+    }));
+    HIPCHK(c, hipGetLastError());
+    return VBMF_OK;
+}
+
+static int launch_retile(vbmf_ctx* c, int which) {
+    const Dims& d = which == 0 ? c->d1 : c->d2;
+    const float* Fac = which == 0 ? c->A32 : c->B32[c->bcur];
+    uint4* Ft = which == 0 ? c->FA : c->FB;
+    const int grid = (d.XT + 3) / 4;
+    DISPATCH_MODE(c->mode, DISPATCH_NH(c->NH, {
+        hipLaunchKernelGGL((retile_kernel<MODEc, NHc>), dim3(grid), dim3(256), 0, c->stream, Fac, Ft, d.XT);
+    }));
+    HIPCHK(c, hipGetLastError());
+    return VBMF_OK;
+}
+
+// Gram of A (which=0) or of B with optional delta-Gram against prev (which=1) into the state block.
+static int launch_gram(vbmf_ctx* c, int which, const float* cur, const float* prev, bool gated) {
+    const Dims& d = which == 0 ? c->d1 : c->d2;
+    const int nchunk = cdiv(d.XT, c->tiles_per_chunk);
+    const int nw = nchunk * c->NH * c->NH;
+    const int* stop = gated ? c->ints + I_STOP : nullptr;
+    DISPATCH_NH(c->NH, {
+        hipLaunchKernelGGL((gram_kernel<NHc>), dim3((nw + 3) / 4), dim3(256), 0, c->stream, cur, prev, c->gslab, d.XT,
+                           c->tiles_per_chunk, nchunk, stop);
+    });
+    const int n = c->Hp * c->Hp;
+    const bool shard = (which == 1 && c->o.nranks > 1);
+    double* outG = shard ? c->gtmp : c->st + (which == 0 ? c->lay.GA() : c->lay.GB());
+    double* outD = which == 0 ? nullptr : (shard ? c->gtmp + n : c->st + c->lay.GD());
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3((2 * n + 255) / 256), dim3(256), 0, c->stream, c->gslab, nchunk, n,
+                       outG, outD, stop);
+    HIPCHK(c, hipGetLastError());
+    if (shard) {
+        if (!c->comm_ready) FAIL(c, VBMF_ERR_COMM, "nranks > 1 but vbmf_comm_init was not called");
+        NCCLCHK(c, ncclAllReduce(c->gtmp, c->gtmp, 2 * (size_t)n, ncclDouble, ncclSum, c->comm, c->stream));
+        // gated copy into the state (after `stop` the state must stay frozen)
+        hipLaunchKernelGGL(gated_copy_kernel, dim3((2 * n + 255) / 256), dim3(256), 0, c->stream, c->gtmp,
+                           c->st + c->lay.GB(), 2 * n, stop);
+        HIPCHK(c, hipGetLastError());
+    }
+    return VBMF_OK;
+}
+
+static int ctrl_threads(int H) { return H <= 16 ? 64 : (H <= 32 ? 256 : 1024); }
+
+static int launch_ctrl_cov(vbmf_ctx* c, int which) {
+    const int H = (int)c->H;
+    const size_t need = ((size_t)H * H + 2 * H) * sizeof(double);
+    const int use_lds = need <= (size_t)c->lds_limit;
+    const double N = which == 0 ? (double)c->Lg : (double)c->M;
+    hipLaunchKernelGGL(ctrl_cov_kernel, dim3(1), dim3(ctrl_threads(H)), use_lds ? need : 0, c->stream, c->st, c->lay, H,
+                       which, N, which == 0 ? c->SA32 : c->SB32, c->ints, use_lds);
+    HIPCHK(c, hipGetLastError());
+    return VBMF_OK;
+}
+
+static int launch_eig(vbmf_ctx* c, int do_d, int do_b) {
+    const int H = (int)c->H;
+    const int n = (H + 1) & ~1;
+    const size_t need = ((size_t)n * n + n) * sizeof(double);
+    const int use_lds = need <= (size_t)c->lds_limit && n <= 256;
+    const int spectral = (c->o.reference_compat & VBMF_COMPAT_SPECTRAL_DELTA) ? 1 : 0;
+    hipLaunchKernelGGL(eig_kernel, dim3(2), dim3(ctrl_threads(H)), use_lds ? need : 0, c->stream, c->st, c->lay, H,
+                       spectral, do_d, do_b, c->ints, use_lds);
+    HIPCHK(c, hipGetLastError());
+    return VBMF_OK;
+}
+
+static int launch_ctrl_end(vbmf_ctx* c, int flags, double eps, double* trace) {
+    hipLaunchKernelGGL(ctrl_end_kernel, dim3(1), dim3(256), 0, c->stream, c->st, c->lay, (int)c->H, (double)c->Lg,
+                       (double)c->M, flags, eps, trace, c->ints);
+    HIPCHK(c, hipGetLastError());
+    return VBMF_OK;
+}
+
+static int ensure_ready(vbmf_ctx* c) {
+    if (!c->haveY) FAIL(c, VBMF_ERR_INVALID, "no Y: call vbmf_set_Y or vbmf_set_Y_synthetic first");
+    if (!c->haveState) FAIL(c, VBMF_ERR_INVALID, "no state: call vbmf_set_state first");
+    if (c->o.nranks > 1 && !c->comm_ready) FAIL(c, VBMF_ERR_COMM, "nranks > 1 but vbmf_comm_init was not called");
+    if (!c->trYY_reduced) {
+        double* dst = c->st + c->lay.scal() + S_TRYY;
+        HIPCHK(c, hipMemcpyAsync(dst, &c->trYY_local, sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        NCCLCHK(c, ncclAllReduce(dst, dst, 1, ncclDouble, ncclSum, c->comm, c->stream));
+        c->trYY_reduced = true;
+    }
+    return VBMF_OK;
+}
+
+static int ensure_gram_A(vbmf_ctx* c) {
+    if (c->gA_valid) return VBMF_OK;
+    TRY(launch_gram(c, 0, c->A32, nullptr, false));
+    c->gA_valid = true;
+    return VBMF_OK;
+}
+static int ensure_gram_B(vbmf_ctx* c) {
+    if (c->gB_valid) return VBMF_OK;
+    TRY(launch_gram(c, 1, c->B32[c->bcur], nullptr, false));
+    c->gB_valid = true;
+    return VBMF_OK;
+}
+
+static int do_update_A(vbmf_ctx* c) {
+    TRY(ensure_gram_B(c));
+    TRY(launch_ctrl_cov(c, 0));
+    TRY(launch_stream(c, 0));
+    if (c->o.nranks > 1) {
+        const long long n = (long long)c->Hp * c->d1.XT * 32;
+        hipLaunchKernelGGL(slab_sum_kernel, dim3(grid_for(n)), dim3(256), 0, c->stream, c->P, c->d1.nsplit, n, c->Pred, n,
+                           c->ints + I_STOP);
+        HIPCHK(c, hipGetLastError());
+        NCCLCHK(c, ncclAllReduce(c->Pred, c->Pred, (size_t)n, ncclFloat, ncclSum, c->comm, c->stream));
+        TRY(launch_post(c, 0, c->Pred, 1));
+    } else {
+        TRY(launch_post(c, 0, c->P, c->d1.nsplit));
+    }
+    TRY(launch_gram(c, 0, c->A32, nullptr, true));
+    c->gA_valid = true;
+    c->P_valid = true;
+    c->kb_identity = false;
+    return VBMF_OK;
+}
+
+static int do_update_B(vbmf_ctx* c) {
+    TRY(ensure_gram_A(c));
+    TRY(launch_ctrl_cov(c, 1));
+    TRY(launch_stream(c, 1));
+    TRY(launch_post(c, 1, c->Q, c->d2.nsplit));
+    TRY(launch_gram(c, 1, c->B32[c->bcur ^ 1], c->B32[c->bcur], true));
+    c->bcur ^= 1;
+    c->gB_valid = true;
+    c->P_valid = false;
+    c->kb_identity = true;
+    return VBMF_OK;
+}
+
+// make scal[S_TRDOT] = tr(Y'BA') when the Gram identity is not available; returns the ctrl_end flag
+static int prepare_trYBA(vbmf_ctx* c, int* flag) {
+    if (c->kb_identity) { *flag = 16; return VBMF_OK; }
+    double* dst = c->st + c->lay.scal() + S_TRDOT;
+    HIPCHK(c, hipMemsetAsync(dst, 0, sizeof(double), c->stream));
+    if (c->P_valid) {
+        const float* In = c->o.nranks > 1 ? c->Pred : c->P;
+        const int ns = c->o.nranks > 1 ? 1 : c->d1.nsplit;
+        const long long ld = (long long)c->d1.XT * 32;
+        hipLaunchKernelGGL(dot_kernel, dim3(grid_for(c->M, 256, 1024)), dim3(256), 0, c->stream, In, ld, ns,
+                           (long long)c->Hp * ld, c->A32, c->Hp, (long long)c->M, dst);
+    } else {
+        TRY(launch_stream(c, 1));
+        const long long ld = (long long)c->d2.XT * 32;
+        hipLaunchKernelGGL(dot_kernel, dim3(grid_for(c->L, 256, 1024)), dim3(256), 0, c->stream, c->Q, ld, c->d2.nsplit,
+                           (long long)c->Hp * ld, c->B32[c->bcur], c->Hp, (long long)c->L, dst);
+        if (c->o.nranks > 1) NCCLCHK(c, ncclAllReduce(dst, dst, 1, ncclDouble, ncclSum, c->comm, c->stream));
+    }
+    HIPCHK(c, hipGetLastError());
+    *flag = 0;
+    return VBMF_OK;
+}
+
+static int check_device_err(vbmf_ctx* c) {
+    HIPCHK(c, hipMemcpyAsync(c->ints_host, c->ints, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->ints_host[I_ERR]) {
+        int zero = 0;
+        hipMemcpy(c->ints + I_ERR, &zero, sizeof(int), hipMemcpyHostToDevice);
+        FAIL(c, VBMF_ERR_NUMERIC, "non-positive or non-finite pivot while inverting an H x H posterior precision");
+    }
+    return VBMF_OK;
+}
+
+__global__ void logdet_kernel(double* st, StateLayout lay, int H, int which, int use_lds) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ int err;
+    if (threadIdx.x == 0) err = 0;
+    double* W = use_lds ? lds : (st + lay.W0());
+    double* aux = use_lds ? (lds + (long long)H * H) : (st + lay.W1());
+    const double* S = st + (which == 0 ? lay.SA() : lay.SB());
+    for (int t = threadIdx.x; t < H * H; t += blockDim.x) W[t] = S[(long long)(t / H) * lay.Hp + (t % H)];
+    __syncthreads();
+    const double ld = gj_inverse_spd(W, H, aux, &err);
+    __syncthreads();
+    if (threadIdx.x == 0) st[lay.scal() + (which == 0 ? S_LOGDET_SA : S_LOGDET_SB)] = err ? -INFINITY : ld;
+}
+
+// ================================================================================================
+extern "C" {
+
+void vbmf_default_opts(vbmf_opts* o) {
+    memset(o, 0, sizeof *o);
+    o->struct_size = (int32_t)sizeof(vbmf_opts);
+    o->y_dtype = VBMF_Y_BF16;
+    o->factor_dtype = VBMF_FACTOR_AUTO;
+    o->variant = VBMF_VARIANT_BASIC;
+    o->reference_compat = VBMF_COMPAT_DEFAULT;
+    o->nranks = 1;
+}
+
+const char* vbmf_last_error(const vbmf_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int vbmf_destroy(vbmf_ctx* c) {
+    if (!c) return VBMF_OK;
+    hipSetDevice(c->o.device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    prof_harvest(c);
+    if (c->comm) ncclCommDestroy(c->comm);
+    void* bufs[] = {c->Y1, c->Y2, c->FA, c->FB, c->P, c->Q, c->Pred, c->A32, c->B32[0], c->B32[1], c->SA32,
+                    c->SB32, c->gslab, c->st, c->gtmp, c->ints, c->mask};
+    for (void* b : bufs) if (b) hipFree(b);
+    if (c->ints_host) hipHostFree(c->ints_host);
+    if (c->scal_host) hipHostFree(c->scal_host);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return VBMF_OK;
+}
+
+int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts* opts) {
+    if (!out) return VBMF_ERR_INVALID;
+    *out = nullptr;
+    vbmf_ctx* c = new vbmf_ctx();
+    auto bail = [&](int code) { g_create_error = c->err; vbmf_destroy(c); return code; };
+    if (opts) {
+        if (opts->struct_size != (int32_t)sizeof(vbmf_opts)) { c->err = "vbmf_opts.struct_size mismatch"; return bail(VBMF_ERR_INVALID); }
+        c->o = *opts;
+    } else {
+        vbmf_default_opts(&c->o);
+    }
+    if (L <= 0 || M <= 0 || H <= 0) { c->err = "L, M, H must be positive"; return bail(VBMF_ERR_INVALID); }
+    if (H > 256) { c->err = "H > 256 is not supported"; return bail(VBMF_ERR_UNSUPPORTED); }
+    if (c->o.variant != VBMF_VARIANT_BASIC) { c->err = "only the basic variant is built in this round"; return bail(VBMF_ERR_UNSUPPORTED); }
+    if (c->o.nranks < 1 || c->o.rank < 0 || c->o.rank >= c->o.nranks) { c->err = "bad nranks/rank"; return bail(VBMF_ERR_INVALID); }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        c->err = "no HIP device visible: this library has no CPU fallback (MI355X / gfx950 required)";
+        return bail(VBMF_ERR_NO_DEVICE);
+    }
+    if (c->o.device < 0 || c->o.device >= ndev) { c->err = "bad device ordinal"; return bail(VBMF_ERR_INVALID); }
+    hipDeviceProp_t prop;
+    if (hipSetDevice(c->o.device) != hipSuccess || hipGetDeviceProperties(&prop, c->o.device) != hipSuccess) {
+        c->err = "hipSetDevice/hipGetDeviceProperties failed"; return bail(VBMF_ERR_NO_DEVICE);
+    }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        c->err = std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
+        return bail(VBMF_ERR_NO_DEVICE);
+    }
+    c->L = L; c->M = M; c->H = H;
+    c->Lg = c->o.L_global > 0 ? c->o.L_global : L;
+    if (c->o.nranks == 1 && c->Lg != L) { c->err = "L_global != L with nranks == 1"; return bail(VBMF_ERR_INVALID); }
+    c->Hp = (int)rup(H, 32);
+    if (c->Hp == 96) c->Hp = 128;
+    if (c->Hp > 128 && c->Hp < 256) c->Hp = 256;
+    c->NH = c->Hp / 32;
+    if (c->o.y_dtype == VBMF_Y_F32) {
+        if (c->o.factor_dtype != VBMF_FACTOR_AUTO) { c->err = "f32 Y takes f32 factor operands (factor_dtype must be AUTO)"; return bail(VBMF_ERR_INVALID); }
+        c->mode = MODE_F32;
+    } else if (c->o.y_dtype == VBMF_Y_BF16) {
+        c->mode = (c->o.factor_dtype == VBMF_FACTOR_BF16) ? MODE_BF16 : MODE_BF16X2;
+    } else { c->err = "bad y_dtype"; return bail(VBMF_ERR_INVALID); }
+    c->kstep = kstep_of(c->mode);
+    c->npart = npart_of(c->mode);
+    plan_pass(c->d1, M, L, c->kstep, c->NH, c->o.pass1_splits);
+    plan_pass(c->d2, L, M, c->kstep, c->NH, 0);
+    c->Mp = (int64_t)c->d1.XT * 32;
+    c->Lp = (int64_t)c->d2.XT * 32;
+    // the post kernel writes operand tiles for every 32-row tile of the factor: the consumer's KS must cover them
+    if ((int64_t)c->d1.KS * c->kstep < c->Lp || (int64_t)c->d2.KS * c->kstep < c->Mp) { c->err = "internal: tile plan"; return bail(VBMF_ERR_INVALID); }
+    c->lay.Hp = c->Hp;
+
+#define ALLOC(ptr, bytes)                                                                       \
+    do {                                                                                        \
+        hipError_t _e = hipMalloc((void**)&(ptr), (bytes));                                     \
+        if (_e != hipSuccess) { c->err = std::string("hipMalloc failed for " #ptr ": ") + hipGetErrorString(_e); return bail(VBMF_ERR_HIP); } \
+        _e = hipMemset((ptr), 0, (bytes));                                                      \
+        if (_e != hipSuccess) { c->err = "hipMemset failed"; return bail(VBMF_ERR_HIP); }       \
+    } while (0)
+
+    const size_t slack = (size_t)PIPE_D * 64;
+    c->nY1 = (size_t)c->d1.XT * c->d1.KS * 64 + slack * 2;
+    c->nY2 = (size_t)c->d2.XT * c->d2.KS * 64 + slack * 2;
+    c->nFB = ((size_t)c->d1.KS + PIPE_D) * c->npart * c->NH * 64;
+    c->nFA = ((size_t)c->d2.KS + PIPE_D) * c->npart * c->NH * 64;
+    ALLOC(c->Y1, c->nY1 * 16);
+    ALLOC(c->Y2, c->nY2 * 16);
+    ALLOC(c->FB, c->nFB * 16);
+    ALLOC(c->FA, c->nFA * 16);
+    ALLOC(c->P, (size_t)c->d1.nsplit * c->Hp * c->Mp * 4);
+    ALLOC(c->Q, (size_t)c->d2.nsplit * c->Hp * c->Lp * 4);
+    if (c->o.nranks > 1) ALLOC(c->Pred, (size_t)c->Hp * c->Mp * 4);
+    ALLOC(c->A32, (size_t)c->Mp * c->Hp * 4);
+    ALLOC(c->B32[0], (size_t)c->Lp * c->Hp * 4);
+    ALLOC(c->B32[1], (size_t)c->Lp * c->Hp * 4);
+    ALLOC(c->SA32, (size_t)c->Hp * c->Hp * 4);
+    ALLOC(c->SB32, (size_t)c->Hp * c->Hp * 4);
+    const int nchunk = std::max(cdiv(c->d1.XT, c->tiles_per_chunk), cdiv(c->d2.XT, c->tiles_per_chunk));
+    ALLOC(c->gslab, (size_t)nchunk * 2 * c->Hp * c->Hp * 4);
+    ALLOC(c->st, (size_t)c->lay.total() * 8);
+    ALLOC(c->gtmp, (size_t)2 * c->Hp * c->Hp * 8);
+    ALLOC(c->ints, 16 * sizeof(int));
+    ALLOC(c->mask, (size_t)c->Mp);
+#undef ALLOC
+    if (hipHostMalloc((void**)&c->ints_host, 16 * sizeof(int)) != hipSuccess ||
+        hipHostMalloc((void**)&c->scal_host, 32 * sizeof(double)) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        c->err = "pinned alloc / stream create failed"; return bail(VBMF_ERR_HIP);
+    }
+    // large dynamic LDS for the H x H control kernels (160 KiB per CU on gfx950)
+    c->lds_limit = 160 * 1024 - 4096;
+    if (hipFuncSetAttribute((const void*)ctrl_cov_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit) != hipSuccess ||
+        hipFuncSetAttribute((const void*)eig_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit) != hipSuccess) {
+        c->lds_limit = 64 * 1024 - 4096;
+        (void)hipGetLastError();
+    }
+    *out = c;
+    return VBMF_OK;
+}
+
+// ---- Y -----------------------------------------------------------------------------------------
+}  // extern "C"
+
+template <class Src>
+static int build_tiles(vbmf_ctx* c, const Src& src, int64_t m0, int64_t m1, double* sumsq) {
+    // pass-1 copy: x tiles covering columns [m0,m1), all k-steps; pass-2 copy: all x tiles, k-steps of [m0,m1)
+    const int xt0 = (int)(m0 / 32), xt1 = (m1 >= c->M) ? c->d1.XT : (int)(m1 / 32);
+    const int ks0 = (int)(m0 / c->kstep), ks1 = (m1 >= c->M) ? c->d2.KS : (int)(m1 / c->kstep);
+    const int64_t n1 = (int64_t)(xt1 - xt0) * c->d1.KS * 64, n2 = (int64_t)c->d2.XT * (ks1 - ks0) * 64;
+    DISPATCH_MODE(c->mode, {
+        constexpr int TM = (MODEc == MODE_F32) ? MODE_F32 : MODE_BF16;
+        hipLaunchKernelGGL((tile_y_kernel<TM, false, Src>), dim3(grid_for(n1, 256, 16384)), dim3(256), 0, c->stream, c->Y1,
+                           src, xt0, xt1, 0, c->d1.KS, c->d1.KS, (double*)nullptr);
+        hipLaunchKernelGGL((tile_y_kernel<TM, true, Src>), dim3(grid_for(n2, 256, 16384)), dim3(256), 0, c->stream, c->Y2,
+                           src, 0, c->d2.XT, ks0, ks1, c->d2.KS, sumsq);
+    });
+    HIPCHK(c, hipGetLastError());
+    return VBMF_OK;
+}
+
+static int finish_Y(vbmf_ctx* c) {
+    double* tr = c->st + c->lay.scal() + S_TRYY;
+    HIPCHK(c, hipMemcpyAsync(c->scal_host, tr, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->trYY_local = c->scal_host[0];
+    c->trYY_reduced = (c->o.nranks == 1);
+    c->haveY = true;
+    c->P_valid = false;
+    c->kb_identity = false;
+    return VBMF_OK;
+}
+
+extern "C" {
+
+int vbmf_set_Y(vbmf_ctx* c, const double* Y, int64_t ldY) {
+    if (!c) return VBMF_ERR_INVALID;
+    if (!Y || ldY < c->L) FAIL(c, VBMF_ERR_INVALID, "vbmf_set_Y: null Y or ldY < L");
+    HIPCHK(c, hipSetDevice(c->o.device));
+    double* tr = c->st + c->lay.scal() + S_TRYY;
+    HIPCHK(c, hipMemsetAsync(tr, 0, sizeof(double), c->stream));
+    int64_t mc = std::max<int64_t>(32, ((int64_t)(256ll << 20) / (c->L * 8)) / 32 * 32);
+    mc = std::min<int64_t>(mc, rup(c->M, 32));
+    double* stage = nullptr;
+    HIPCHK(c, hipMalloc((void**)&stage, (size_t)c->L * mc * 8));
+    int rc = VBMF_OK;
+    for (int64_t m0 = 0; m0 < c->M && rc == VBMF_OK; m0 += mc) {
+        const int64_t m1 = std::min(c->M, m0 + mc);
+        hipError_t e = hipMemcpy2DAsync(stage, (size_t)c->L * 8, Y + m0 * ldY, (size_t)ldY * 8, (size_t)c->L * 8,
+                                        (size_t)(m1 - m0), hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) { c->err = std::string("hipMemcpy2DAsync: ") + hipGetErrorString(e); rc = VBMF_ERR_HIP; break; }
+        ColMajorF64Src src{stage, c->L, m0, m1 - m0, c->L, c->M};
+        rc = build_tiles(c, src, m0, m1, tr);
+        if (rc == VBMF_OK && hipStreamSynchronize(c->stream) != hipSuccess) { c->err = "sync failed in vbmf_set_Y"; rc = VBMF_ERR_HIP; }
+    }
+    hipFree(stage);
+    if (rc != VBMF_OK) return rc;
+    return finish_Y(c);
+}
+
+int vbmf_set_Y_synthetic(vbmf_ctx* c, uint64_t seed, int64_t Hstar, double noise_std) {
+    if (!c) return VBMF_ERR_INVALID;
+    if (Hstar <= 0) FAIL(c, VBMF_ERR_INVALID, "Hstar must be positive");
+    HIPCHK(c, hipSetDevice(c->o.device));
+    double* tr = c->st + c->lay.scal() + S_TRYY;
+    HIPCHK(c, hipMemsetAsync(tr, 0, sizeof(double), c->stream));
+    SynthSrc src{SynthGen{seed, (long long)Hstar, (long long)c->M, (float)noise_std}, c->L, c->M, c->o.row_offset};
+    TRY(build_tiles(c, src, 0, c->M, tr));
+    return finish_Y(c);
+}
+
+int vbmf_get_Y(vbmf_ctx* c, double* Y, int64_t ldY, int64_t row0, int64_t nrows) {
+    if (!c) return VBMF_ERR_INVALID;
+    if (!c->haveY) FAIL(c, VBMF_ERR_INVALID, "no Y");
+    if (!Y || row0 < 0 || nrows <= 0 || row0 + nrows > c->L || ldY < nrows) FAIL(c, VBMF_ERR_INVALID, "vbmf_get_Y: bad range");
+    HIPCHK(c, hipSetDevice(c->o.device));
+    // column chunks of a multiple of 32 (= whole k-steps of the pass-2 copy)
+    int64_t mc = std::max<int64_t>(32, ((int64_t)(256ll << 20) / (nrows * 8)) / 32 * 32);
+    mc = std::min<int64_t>(mc, rup(c->M, 32));
+    double* tmp = nullptr;
+    HIPCHK(c, hipMalloc((void**)&tmp, (size_t)nrows * mc * 8));
+    for (int64_t m0 = 0; m0 < c->M; m0 += mc) {
+        const int64_t m1 = std::min(c->M, m0 + mc);
+        // shifting the tile pointer by whole k-steps makes the kernel's column 0 equal to column m0
+        const uint4* base = c->Y2 + (size_t)(m0 / c->kstep) * 64;
+        DISPATCH_MODE(c->mode, {
+            constexpr int TM = (MODEc == MODE_F32) ? MODE_F32 : MODE_BF16;
+            hipLaunchKernelGGL((untile_y_kernel<TM>), dim3(grid_for(nrows * (m1 - m0))), dim3(256), 0, c->stream, base,
+                               tmp, (long long)nrows, (long long)row0, (long long)nrows, (long long)(m1 - m0), c->d2.KS);
+        });
+        hipError_t e = hipMemcpy2DAsync(Y + m0 * ldY, (size_t)ldY * 8, tmp, (size_t)nrows * 8, (size_t)nrows * 8,
+                                        (size_t)(m1 - m0), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { hipFree(tmp); FAIL(c, VBMF_ERR_HIP, "vbmf_get_Y copy failed: %s", hipGetErrorString(e)); }
+    }
+    hipFree(tmp);
+    return VBMF_OK;
+}
+
+int vbmf_get_trYY(vbmf_ctx* c, double* trYY) {
+    if (!c || !trYY) return VBMF_ERR_INVALID;
+    if (!c->haveY) FAIL(c, VBMF_ERR_INVALID, "no Y");
+    HIPCHK(c, hipSetDevice(c->o.device));
+    if (c->o.nranks > 1 && !c->trYY_reduced) { *trYY = c->trYY_local; return VBMF_OK; }
+    HIPCHK(c, hipMemcpyAsync(c->scal_host, c->st + c->lay.scal() + S_TRYY, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *trYY = c->scal_host[0];
+    return VBMF_OK;
+}
+
+// ---- state -------------------------------------------------------------------------------------
+static int upload_factor(vbmf_ctx* c, const double* src, int64_t ld, int64_t X, int64_t Xp, float* dst) {
+    double* tmp = nullptr;
+    HIPCHK(c, hipMalloc((void**)&tmp, (size_t)X * c->H * 8));
+    hipError_t e = hipMemcpy2DAsync(tmp, (size_t)X * 8, src, (size_t)ld * 8, (size_t)X * 8, (size_t)c->H,
+                                    hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(pack_factor_kernel, dim3(grid_for(Xp * c->Hp)), dim3(256), 0, c->stream, tmp, (long long)X,
+                           (long long)X, (int)c->H, c->Hp, (long long)Xp, dst);
+        e = hipStreamSynchronize(c->stream);
+    }
+    hipFree(tmp);
+    if (e != hipSuccess) FAIL(c, VBMF_ERR_HIP, "factor upload failed: %s", hipGetErrorString(e));
+    return VBMF_OK;
+}
+static int download_factor(vbmf_ctx* c, const float* src, int64_t X, double* dst, int64_t ld) {
+    double* tmp = nullptr;
+    HIPCHK(c, hipMalloc((void**)&tmp, (size_t)X * c->H * 8));
+    hipLaunchKernelGGL(unpack_factor_kernel, dim3(grid_for(X * c->H)), dim3(256), 0, c->stream, src, c->Hp, (long long)X,
+                       (int)c->H, tmp, (long long)X);
+    hipError_t e = hipMemcpy2DAsync(dst, (size_t)ld * 8, tmp, (size_t)X * 8, (size_t)X * 8, (size_t)c->H,
+                                    hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(tmp);
+    if (e != hipSuccess) FAIL(c, VBMF_ERR_HIP, "factor download failed: %s", hipGetErrorString(e));
+    return VBMF_OK;
+}
+
+static int upload_small(vbmf_ctx* c, const double* srcHxH, long long off, bool matrix) {
+    // H x H column-major (ld=H) -> Hp-strided block; symmetric matrices, so row/column-major agree
+    std::vector<double> buf(matrix ? (size_t)c->Hp * c->Hp : (size_t)c->Hp, matrix ? 0.0 : 1.0);
+    if (matrix) {
+        for (int64_t j = 0; j < c->H; ++j)
+            for (int64_t i = 0; i < c->H; ++i) buf[(size_t)i * c->Hp + j] = srcHxH[i + j * c->H];
+    } else {
+        for (int64_t i = 0; i < c->H; ++i) buf[i] = srcHxH[i];
+    }
+    HIPCHK(c, hipMemcpy(c->st + off, buf.data(), buf.size() * 8, hipMemcpyHostToDevice));
+    return VBMF_OK;
+}
+
+int vbmf_set_state(vbmf_ctx* c, const double* AHat, int64_t ldA, const double* BHat, int64_t ldB,
+                   const double* SigmaA, const double* SigmaB, const double* CA_diag, const double* CB_diag,
+                   double sigma2, const int64_t* labels0, int64_t nlabels, int64_t H1) {
+    if (!c) return VBMF_ERR_INVALID;
+    if (!AHat || !BHat || !SigmaA || !SigmaB || !CA_diag || !CB_diag) FAIL(c, VBMF_ERR_INVALID, "vbmf_set_state: null pointer");
+    if (ldA < c->M || ldB < c->L) FAIL(c, VBMF_ERR_INVALID, "vbmf_set_state: leading dimension too small");
+    if (H1 < 0 || H1 > c->H || nlabels < 0 || (nlabels > 0 && !labels0)) FAIL(c, VBMF_ERR_INVALID, "vbmf_set_state: bad H1/labels");
+    if (!(sigma2 > 0.0)) FAIL(c, VBMF_ERR_INVALID, "vbmf_set_state: sigma2 must be positive");
+    for (int64_t h = 0; h < c->H; ++h)
+        if (!(CA_diag[h] > 0.0) || !(CB_diag[h] > 0.0)) FAIL(c, VBMF_ERR_INVALID, "vbmf_set_state: CA/CB diagonals must be positive");
+    HIPCHK(c, hipSetDevice(c->o.device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->bcur = 0;
+    TRY(upload_factor(c, AHat, ldA, c->M, c->Mp, c->A32));
+    TRY(upload_factor(c, BHat, ldB, c->L, c->Lp, c->B32[0]));
+    TRY(upload_small(c, SigmaA, c->lay.SA(), true));
+    TRY(upload_small(c, SigmaB, c->lay.SB(), true));
+    TRY(upload_small(c, CA_diag, c->lay.ca(), false));
+    TRY(upload_small(c, CB_diag, c->lay.cb(), false));
+    HIPCHK(c, hipMemcpy(c->st + c->lay.scal() + S_SIGMA2, &sigma2, 8, hipMemcpyHostToDevice));
+    std::vector<unsigned char> mk((size_t)c->Mp, 0);
+    for (int64_t i = 0; i < nlabels; ++i) {
+        if (labels0[i] < 0 || labels0[i] >= c->M) FAIL(c, VBMF_ERR_INVALID, "vbmf_set_state: label %lld out of range", (long long)labels0[i]);
+        mk[(size_t)labels0[i]] = 1;
+    }
+    HIPCHK(c, hipMemcpy(c->mask, mk.data(), mk.size(), hipMemcpyHostToDevice));
+    c->H1 = H1;
+    c->has_mask = (nlabels > 0 && H1 > 0);
+    TRY(launch_retile(c, 0));
+    TRY(launch_retile(c, 1));
+    const int H = (int)c->H;
+    const size_t need = ((size_t)H * H + 2 * H) * sizeof(double);
+    const int use_lds = need <= 60 * 1024;
+    for (int w = 0; w < 2; ++w)
+        hipLaunchKernelGGL(logdet_kernel, dim3(1), dim3(ctrl_threads(H)), use_lds ? need : 0, c->stream, c->st, c->lay, H, w, use_lds);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemsetAsync(c->ints, 0, 16 * sizeof(int), c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->gA_valid = c->gB_valid = c->P_valid = c->kb_identity = false;
+    c->haveState = true;
+    return VBMF_OK;
+}
+
+int vbmf_get_state(vbmf_ctx* c, double* AHat, int64_t ldA, double* BHat, int64_t ldB, double* SigmaA,
+                   double* SigmaB, double* CA_diag, double* CB_diag, double* sigma2) {
+    if (!c) return VBMF_ERR_INVALID;
+    if (!c->haveState) FAIL(c, VBMF_ERR_INVALID, "no state");
+    HIPCHK(c, hipSetDevice(c->o.device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (AHat) { if (ldA < c->M) FAIL(c, VBMF_ERR_INVALID, "ldA < M"); TRY(download_factor(c, c->A32, c->M, AHat, ldA)); }
+    if (BHat) { if (ldB < c->L) FAIL(c, VBMF_ERR_INVALID, "ldB < L"); TRY(download_factor(c, c->B32[c->bcur], c->L, BHat, ldB)); }
+    std::vector<double> buf((size_t)c->lay.total());
+    HIPCHK(c, hipMemcpy(buf.data(), c->st, buf.size() * 8, hipMemcpyDeviceToHost));
+    auto mat = [&](long long off, double* dst) {
+        if (!dst) return;
+        for (int64_t j = 0; j < c->H; ++j)
+            for (int64_t i = 0; i < c->H; ++i) dst[i + j * c->H] = buf[(size_t)off + (size_t)i * c->Hp + j];
+    };
+    mat(c->lay.SA(), SigmaA);
+    mat(c->lay.SB(), SigmaB);
+    if (CA_diag) for (int64_t i = 0; i < c->H; ++i) CA_diag[i] = buf[(size_t)c->lay.ca() + i];
+    if (CB_diag) for (int64_t i = 0; i < c->H; ++i) CB_diag[i] = buf[(size_t)c->lay.cb() + i];
+    if (sigma2) *sigma2 = buf[(size_t)c->lay.scal() + S_SIGMA2];
+    return VBMF_OK;
+}
+
+// ---- updates -----------------------------------------------------------------------------------
+int vbmf_step(vbmf_ctx* c, int which) {
+    if (!c) return VBMF_ERR_INVALID;
+    if (which & ~31) FAIL(c, VBMF_ERR_INVALID, "vbmf_step: unknown update bits");
+    HIPCHK(c, hipSetDevice(c->o.device));
+    TRY(ensure_ready(c));
+    if (which & VBMF_STEP_A) TRY(do_update_A(c));
+    if (which & VBMF_STEP_B) TRY(do_update_B(c));
+    int flags = 0;
+    if (which & VBMF_STEP_CA) { TRY(ensure_gram_A(c)); flags |= 1; }
+    if (which & VBMF_STEP_CB) { TRY(ensure_gram_B(c)); flags |= 2; }
+    if (which & VBMF_STEP_SIGMA2) {
+        TRY(ensure_gram_A(c));
+        TRY(ensure_gram_B(c));
+        int f = 0;
+        TRY(prepare_trYBA(c, &f));
+        flags |= 4 | f;
+    }
+    if (flags) {
+        if (!(flags & 4)) { TRY(ensure_gram_A(c)); TRY(ensure_gram_B(c)); flags |= c->kb_identity ? 16 : 0; }
+        TRY(launch_ctrl_end(c, flags, 0.0, nullptr));
+    }
+    return check_device_err(c);
+}
+
+int vbmf_run(vbmf_ctx* c, int64_t niter, double eps, int est_covs, int est_var, int64_t* iters_done,
+             double* d_last, double* trace) {
+    if (!c) return VBMF_ERR_INVALID;
+    if (niter < 0 || niter > (1ll << 30)) FAIL(c, VBMF_ERR_INVALID, "vbmf_run: bad niter");
+    HIPCHK(c, hipSetDevice(c->o.device));
+    TRY(ensure_ready(c));
+    if (iters_done) *iters_done = 0;
+    if (d_last) *d_last = eps + 1.0;                       // src/vbmf.jl:189
+    if (niter == 0) return VBMF_OK;
+    double* trace_dev = nullptr;
+    if (trace) {
+        HIPCHK(c, hipMalloc((void**)&trace_dev, (size_t)niter * 4 * 8));
+        HIPCHK(c, hipMemsetAsync(trace_dev, 0, (size_t)niter * 4 * 8, c->stream));
+    }
+    int init[4] = {0, 0, 0, (int)niter};
+    HIPCHK(c, hipMemcpyAsync(c->ints, init, sizeof init, hipMemcpyHostToDevice, c->stream));
+    // ||B_old||_2 of the first comparison (src/vbmf.jl:187-188: old = params.BHat)
+    int rc = ensure_gram_B(c);
+    if (rc == VBMF_OK) rc = launch_eig(c, 0, 1);
+    if (rc == VBMF_OK) {
+        hipLaunchKernelGGL(copy_scalar_kernel, dim3(1), dim3(1), 0, c->stream, c->st, c->lay, (int)S_LAMB_PREV, (int)S_LAMB_NEW);
+    }
+    const int flags = (est_covs ? 3 : 0) | (est_var ? 4 : 0) | 8 | 16;
+    const int bstart = c->bcur;
+    const int64_t check = 8;
+    int64_t it = 0;
+    bool stopped = false;
+    while (rc == VBMF_OK && it < niter && !stopped) {
+        rc = do_update_A(c);
+        if (rc == VBMF_OK) rc = do_update_B(c);
+        if (rc == VBMF_OK) rc = launch_eig(c, 1, 1);
+        if (rc == VBMF_OK) rc = launch_ctrl_end(c, flags, eps, trace_dev);
+        ++it;
+        if (rc == VBMF_OK && (it % check == 0 || it == niter)) {
+            hipError_t e = hipMemcpyAsync(c->ints_host, c->ints, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) { c->err = std::string("run loop sync: ") + hipGetErrorString(e); rc = VBMF_ERR_HIP; break; }
+            if (c->ints_host[I_STOP] || c->ints_host[I_ERR]) stopped = true;
+        }
+    }
+    if (rc == VBMF_OK) {
+        hipError_t e = hipMemcpyAsync(c->ints_host, c->ints, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(c->scal_host, c->st + c->lay.scal(), 32 * 8, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { c->err = std::string("run readback: ") + hipGetErrorString(e); rc = VBMF_ERR_HIP; }
+    }
+    if (rc == VBMF_OK) {
+        const int done = c->ints_host[I_ITERS];
+        c->bcur = bstart ^ (done & 1);                    // sweeps after `stop` were no-ops on the device
+        if (iters_done) *iters_done = done;
+        if (d_last && done > 0) *d_last = c->scal_host[S_D];
+        if (trace && done > 0) {
+            if (hipMemcpy(trace, trace_dev, (size_t)done * 4 * 8, hipMemcpyDeviceToHost) != hipSuccess) { c->err = "trace copy failed"; rc = VBMF_ERR_HIP; }
+        }
+        if (c->ints_host[I_ERR]) { c->err = "non-positive or non-finite pivot while inverting an H x H posterior precision"; rc = VBMF_ERR_NUMERIC; }
+    }
+    int zero4[4] = {0, 0, 0, 0};
+    hipMemcpy(c->ints, zero4, sizeof zero4, hipMemcpyHostToDevice);
+    if (trace_dev) hipFree(trace_dev);
+    c->gA_valid = c->gB_valid = true;
+    c->P_valid = false;
+    c->kb_identity = true;
+    return rc;
+}
+
+int vbmf_get_YHat(vbmf_ctx* c, double* YHat, int64_t ld) {
+    if (!c) return VBMF_ERR_INVALID;
+    if (!c->haveState) FAIL(c, VBMF_ERR_INVALID, "no state");
+    if (!YHat || ld < c->L) FAIL(c, VBMF_ERR_INVALID, "vbmf_get_YHat: bad arguments");
+    HIPCHK(c, hipSetDevice(c->o.device));
+    int64_t mc = std::max<int64_t>(1, (int64_t)(256ll << 20) / (c->L * 8));
+    mc = std::min(mc, c->M);
+    double* tmp = nullptr;
+    HIPCHK(c, hipMalloc((void**)&tmp, (size_t)c->L * mc * 8));
+    for (int64_t m0 = 0; m0 < c->M; m0 += mc) {
+        const int64_t m1 = std::min(c->M, m0 + mc);
+        hipLaunchKernelGGL(yhat_kernel, dim3(grid_for(c->L * (m1 - m0))), dim3(256), 0, c->stream, c->B32[c->bcur],
+                           c->A32 + (size_t)m0 * c->Hp, c->Hp, (int)c->H, (long long)c->L, (long long)(m1 - m0), tmp,
+                           (long long)c->L);
+        hipError_t e = hipMemcpy2DAsync(YHat + m0 * ld, (size_t)ld * 8, tmp, (size_t)c->L * 8, (size_t)c->L * 8,
+                                        (size_t)(m1 - m0), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { hipFree(tmp); FAIL(c, VBMF_ERR_HIP, "vbmf_get_YHat failed: %s", hipGetErrorString(e)); }
+    }
+    hipFree(tmp);
+    return VBMF_OK;
+}
+
+int vbmf_elbo(vbmf_ctx* c, double* elbo) {
+    if (!c || !elbo) return VBMF_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->o.device));
+    TRY(ensure_ready(c));
+    TRY(ensure_gram_A(c));
+    TRY(ensure_gram_B(c));
+    int f = 0;
+    TRY(prepare_trYBA(c, &f));
+    TRY(launch_ctrl_end(c, f, 0.0, nullptr));
+    HIPCHK(c, hipMemcpyAsync(c->scal_host, c->st + c->lay.scal(), 32 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *elbo = c->scal_host[S_ELBO];
+    return VBMF_OK;
+}
+
+// ---- multi-GPU ---------------------------------------------------------------------------------
+int vbmf_comm_unique_id(void* id128) {
+    if (!id128) return VBMF_ERR_INVALID;
+    static_assert(sizeof(ncclUniqueId) <= VBMF_UNIQUE_ID_BYTES, "unique id size");
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return VBMF_ERR_COMM;
+    memset(id128, 0, VBMF_UNIQUE_ID_BYTES);
+    memcpy(id128, &id, sizeof id);
+    return VBMF_OK;
+}
+
+int vbmf_comm_init(vbmf_ctx* c, const void* id128) {
+    if (!c || !id128) return VBMF_ERR_INVALID;
+    if (c->comm_ready) FAIL(c, VBMF_ERR_INVALID, "communicator already initialised");
+    HIPCHK(c, hipSetDevice(c->o.device));
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    NCCLCHK(c, ncclCommInitRank(&c->comm, c->o.nranks, id, c->o.rank));
+    c->comm_ready = true;
+    return VBMF_OK;
+}
+
+// ---- measurement -------------------------------------------------------------------------------
+int vbmf_profile_enable(vbmf_ctx* c, int on) {
+    if (!c) return VBMF_ERR_INVALID;
+    hipSetDevice(c->o.device);
+    prof_harvest(c);
+    c->prof = on != 0;
+    return VBMF_OK;
+}
+
+int vbmf_profile_read(vbmf_ctx* c, double* out8, int reset) {
+    if (!c || !out8) return VBMF_ERR_INVALID;
+    hipSetDevice(c->o.device);
+    prof_harvest(c);
+    memset(out8, 0, 8 * sizeof(double));
+    out8[0] = c->prof_ms[0]; out8[1] = c->prof_n[0]; out8[2] = c->prof_ms[1]; out8[3] = c->prof_n[1];
+    if (reset) { c->prof_ms[0] = c->prof_ms[1] = 0; c->prof_n[0] = c->prof_n[1] = 0; }
+    return VBMF_OK;
+}
+
+int vbmf_pass_bytes(vbmf_ctx* c, int pass, double* bytes) {
+    if (!c || !bytes || (pass != 1 && pass != 2)) return VBMF_ERR_INVALID;
+    // algorithmic traffic of one launch: Y once in its device dtype, the factor in
+    // (fp32 equivalent), the H-wide result out (fp32)
+    const double ybytes = (c->mode == MODE_F32) ? 4.0 : 2.0;
+    const double LM = (double)c->L * (double)c->M;
+    if (pass == 1) *bytes = LM * ybytes + (double)c->L * c->H * 4.0 + (double)c->M * c->H * 4.0;
+    else *bytes = LM * ybytes + (double)c->M * c->H * 4.0 + (double)c->L * c->H * 4.0;
+    return VBMF_OK;
+}
+
+int vbmf_device_sync(vbmf_ctx* c) {
+    if (!c) return VBMF_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->o.device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VBMF_OK;
+}
+
+}  // extern "C"
