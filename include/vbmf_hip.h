@@ -135,6 +135,18 @@ int vbmf_profile_read(vbmf_ctx* ctx, double* out8, int reset);
 int vbmf_pass_bytes(vbmf_ctx* ctx, int pass, double* bytes);
 int vbmf_device_sync(vbmf_ctx* ctx);
 
+/* ---- test hook: raw 32-bit words of an internal device buffer (layout tests, debugging) ---- */
+#define VBMF_PEEK_P 0      /* pass-1 result slabs  [nsplit][Hp][Mp] fp32 */
+#define VBMF_PEEK_Q 1      /* pass-2 result slabs  [nsplit][Hp][Lp] fp32 */
+#define VBMF_PEEK_A32 2    /* AHat fp32 row-major  [Mp][Hp] */
+#define VBMF_PEEK_B32 3    /* BHat fp32 row-major  [Lp][Hp] */
+#define VBMF_PEEK_FA 4     /* AHat MFMA operand tiles */
+#define VBMF_PEEK_FB 5     /* BHat MFMA operand tiles */
+#define VBMF_PEEK_Y1 6     /* Y tiled for pass 1 */
+#define VBMF_PEEK_Y2 7     /* Y tiled for pass 2 */
+#define VBMF_PEEK_DIMS 8   /* int32 x 16: Hp, NH, mode, XT1, KS1, nsplit1, sps1, XT2, KS2, nsplit2, sps2, kstep, npart */
+int vbmf_debug_peek(vbmf_ctx* ctx, int what, uint32_t* out, int64_t nwords, int64_t word_offset);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,3 +43,22 @@ def compare(tag, pg, po, tol, fields=("AHat", "BHat", "SigmaA", "SigmaB", "CA", 
     bad = {k: v for k, v in errs.items() if not v <= tol.get(k, tol["default"])}
     assert not bad, (tag, bad, errs)
     return errs
+
+
+def bf16_round(Y):
+    """fp64 -> bf16 with ONE round-to-nearest-even (what the device stores), returned as float64."""
+    Y = np.asarray(Y, dtype=np.float64)
+    u = Y.astype(np.float32).view(np.uint32).astype(np.int64)
+    base = u & 0xFFFF0000
+    best = None
+    for off in (-0x10000, 0, 0x10000):
+        cu = base + off
+        cand = (cu & 0xFFFFFFFF).astype(np.uint32).view(np.float32).astype(np.float64)
+        err = np.abs(cand - Y)
+        even = ((cu >> 16) & 1) == 0
+        if best is None:
+            best, berr, beven = cand, err, even
+        else:
+            take = (err < berr) | ((err == berr) & even & ~beven)
+            best = np.where(take, cand, best); berr = np.where(take, err, berr); beven = np.where(take, even, beven)
+    return best

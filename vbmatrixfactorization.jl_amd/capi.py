@@ -23,8 +23,9 @@ SYMBOLS = [
     "vbmf_default_opts", "vbmf_create", "vbmf_destroy", "vbmf_last_error", "vbmf_set_Y", "vbmf_set_Y_synthetic",
     "vbmf_get_Y", "vbmf_get_trYY", "vbmf_set_state", "vbmf_get_state", "vbmf_step", "vbmf_run", "vbmf_get_YHat",
     "vbmf_elbo", "vbmf_comm_unique_id", "vbmf_comm_init", "vbmf_profile_enable", "vbmf_profile_read",
-    "vbmf_pass_bytes", "vbmf_device_sync",
+    "vbmf_pass_bytes", "vbmf_device_sync", "vbmf_debug_peek",
 ]
+PEEK_P, PEEK_Q, PEEK_A32, PEEK_B32, PEEK_FA, PEEK_FB, PEEK_Y1, PEEK_Y2, PEEK_DIMS = range(9)
 
 
 class VbmfOpts(C.Structure):
@@ -77,6 +78,7 @@ def lib():
     L.vbmf_profile_read.argtypes = [vp, dp, i32]
     L.vbmf_pass_bytes.argtypes = [vp, i32, dp]
     L.vbmf_device_sync.argtypes = [vp]
+    L.vbmf_debug_peek.argtypes = [vp, i32, C.POINTER(C.c_uint32), i64, i64]
     for name in SYMBOLS:
         if name not in ("vbmf_default_opts", "vbmf_last_error"):
             getattr(L, name).restype = C.c_int
@@ -222,6 +224,16 @@ class Context:
         v = C.c_double()
         self._chk(self._lib.vbmf_pass_bytes(self._h, p, C.byref(v)))
         return v.value
+
+    def peek(self, what, nwords, offset=0, dtype=np.uint32):
+        out = np.zeros(nwords, dtype=np.uint32)
+        self._chk(self._lib.vbmf_debug_peek(self._h, what, out.ctypes.data_as(C.POINTER(C.c_uint32)), nwords, offset))
+        return out.view(dtype)
+
+    def dims(self):
+        v = self.peek(PEEK_DIMS, 16, dtype=np.int32)
+        keys = ["Hp", "NH", "mode", "XT1", "KS1", "nsplit1", "sps1", "XT2", "KS2", "nsplit2", "sps2", "kstep", "npart"]
+        return dict(zip(keys, (int(x) for x in v)))
 
     def sync(self):
         self._chk(self._lib.vbmf_device_sync(self._h))

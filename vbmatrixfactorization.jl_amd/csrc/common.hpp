@@ -44,6 +44,11 @@ __host__ __device__ __forceinline__ int kperm(int mode, int half, int e) {
     return mode == MODE_F32 ? (4 * half + e) : (8 * (e >> 2) + 4 * half + (e & 3));
 }
 
+// NOTE: never apply __builtin_bit_cast directly to an ext_vector element (v[i]): clang (ROCm 7.2)
+// then reads element 0.  Always go through a by-value scalar, as these helpers do.
+__device__ __forceinline__ unsigned fbits(float f) { return __builtin_bit_cast(unsigned, f); }
+__device__ __forceinline__ float bitsf(unsigned u) { return __builtin_bit_cast(float, u); }
+
 __device__ __forceinline__ unsigned short f2bf(float f) {      // RNE, NaN-preserving (v_cvt_pk_bf16_f32)
     __bf16 b = (__bf16)f;
     return __builtin_bit_cast(unsigned short, b);

@@ -18,16 +18,18 @@
 namespace vbmf {
 
 // ---- emit the operand tiles of one 32-row accumulator tile (rows = k of the next pass) ----------
+// In the bf16 modes v is REPLACED by the value the tiles encode (hi, or hi+lo -- exactly representable
+// in fp32), so the fp32 factor kept for the Grams is bit-for-bit what the next MFMA pass multiplies:
+// the residual ||Y||^2 - 2tr(Y'BA') + tr(A'A B'B) then cancels consistently (src/vbmf.jl:154-156).
 template <int MODE, int NH>
-__device__ __forceinline__ void write_factor_tiles(uint4* __restrict__ Ft, const f32x16& v, int xt, int nh,
-                                                   int lane) {
+__device__ __forceinline__ void write_factor_tiles(uint4* __restrict__ Ft, f32x16& v, int xt, int nh, int lane) {
     constexpr int NPART = ModeTraits<MODE>::NPART;
     if constexpr (MODE == MODE_F32) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {                      // k-step (8 rows) 4*xt+g, element e = r&3
             uint4 o;
-            o.x = __builtin_bit_cast(unsigned, v[4 * g + 0]); o.y = __builtin_bit_cast(unsigned, v[4 * g + 1]);
-            o.z = __builtin_bit_cast(unsigned, v[4 * g + 2]); o.w = __builtin_bit_cast(unsigned, v[4 * g + 3]);
+            const float e0 = v[4 * g + 0], e1 = v[4 * g + 1], e2 = v[4 * g + 2], e3 = v[4 * g + 3];
+            o.x = fbits(e0); o.y = fbits(e1); o.z = fbits(e2); o.w = fbits(e3);
             Ft[((long long)(4 * xt + g) * NH + nh) * 64 + lane] = o;
         }
     } else {
@@ -38,7 +40,14 @@ __device__ __forceinline__ void write_factor_tiles(uint4* __restrict__ Ft, const
             for (int e = 0; e < 8; ++e) {
                 const float f = v[8 * s + e];
                 hi[e] = f2bf(f);
-                lo[e] = f2bf(f - bf2f(hi[e]));
+                const float fh = bf2f(hi[e]);
+                if constexpr (NPART == 2) {
+                    lo[e] = f2bf(f - fh);
+                    v[8 * s + e] = fh + bf2f(lo[e]);
+                } else {
+                    lo[e] = 0;
+                    v[8 * s + e] = fh;
+                }
             }
             uint4 o;
             o.x = hi[0] | ((unsigned)hi[1] << 16); o.y = hi[2] | ((unsigned)hi[3] << 16);
@@ -100,14 +109,14 @@ __global__ __launch_bounds__(256) void post_kernel(const float* __restrict__ In,
             for (int r = 0; r < 16; ++r)
                 if (mask[x0 + rho(r, half)]) acc[h][r] = 0.f;
         }
+        write_factor_tiles<MODE, NH>(Ft, acc[h], xt, h, lane);
 #pragma unroll
         for (int r = 0; r < 16; ++r) Fac[(x0 + rho(r, half)) * Hp + hcol] = acc[h][r];
-        write_factor_tiles<MODE, NH>(Ft, acc[h], xt, h, lane);
     }
 }
 
 template <int MODE, int NH>
-__global__ __launch_bounds__(256) void retile_kernel(const float* __restrict__ Fac, uint4* __restrict__ Ft, int XT) {
+__global__ __launch_bounds__(256) void retile_kernel(float* __restrict__ Fac, uint4* __restrict__ Ft, int XT) {
     constexpr int Hp = NH * 32;
     const int lane = threadIdx.x & 63;
     const int xt = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -120,6 +129,10 @@ __global__ __launch_bounds__(256) void retile_kernel(const float* __restrict__ F
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = Fac[(x0 + rho(r, half)) * Hp + h * 32 + c];
         write_factor_tiles<MODE, NH>(Ft, v, xt, h, lane);
+        if constexpr (MODE != MODE_F32) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Fac[(x0 + rho(r, half)) * Hp + h * 32 + c] = v[r];
+        }
     }
 }
 

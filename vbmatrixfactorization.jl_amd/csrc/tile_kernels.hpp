@@ -17,16 +17,16 @@ namespace vbmf {
 struct ColMajorF64Src {
     const double* buf; long long ld; long long m0, mc;   // staging chunk: columns [m0, m0+mc)
     long long L, M;
-    __device__ __forceinline__ float operator()(long long l, long long m) const {
-        if (l >= L || m >= M) return 0.f;
-        return (float)buf[(m - m0) * ld + l];
+    __device__ __forceinline__ double operator()(long long l, long long m) const {
+        if (l >= L || m >= M) return 0.0;
+        return buf[(m - m0) * ld + l];
     }
 };
 struct SynthSrc {
     SynthGen g; long long L, M, row_offset;
-    __device__ __forceinline__ float operator()(long long l, long long m) const {
-        if (l >= L || m >= M) return 0.f;
-        return g(l + row_offset, m);
+    __device__ __forceinline__ double operator()(long long l, long long m) const {
+        if (l >= L || m >= M) return 0.0;
+        return (double)g(l + row_offset, m);
     }
 };
 
@@ -49,7 +49,8 @@ __global__ __launch_bounds__(256) void tile_y_kernel(uint4* __restrict__ out, Sr
         const int xt = xt0 + (int)(q / nks);
         const int c = lane & 31, half = lane >> 5;
         const long long x = (long long)xt * 32 + c;
-        float v[NE];
+        // values are rounded ONCE, from the source's fp64, to the device dtype (round-to-nearest-even)
+        double v[NE];
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
             const long long k = (long long)ks * KSTEP + kperm(MODE, half, e);
@@ -57,14 +58,19 @@ __global__ __launch_bounds__(256) void tile_y_kernel(uint4* __restrict__ out, Sr
         }
         uint4 o;
         if (MODE == MODE_F32) {
-            o.x = __builtin_bit_cast(unsigned, v[0]); o.y = __builtin_bit_cast(unsigned, v[1]);
-            o.z = __builtin_bit_cast(unsigned, v[2]); o.w = __builtin_bit_cast(unsigned, v[3]);
+            float f[4];
 #pragma unroll
-            for (int e = 0; e < NE; ++e) acc += (double)v[e] * (double)v[e];
+            for (int e = 0; e < 4; ++e) { f[e] = (float)v[e]; acc += (double)f[e] * (double)f[e]; }
+            o.x = fbits(f[0]); o.y = fbits(f[1]); o.z = fbits(f[2]); o.w = fbits(f[3]);
         } else {
             unsigned short b[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { b[e] = f2bf(v[e]); const float r = bf2f(b[e]); acc += (double)r * (double)r; }
+            for (int e = 0; e < 8; ++e) {
+                const __bf16 q = (__bf16)v[e];
+                b[e] = __builtin_bit_cast(unsigned short, q);
+                const float r = bf2f(b[e]);
+                acc += (double)r * (double)r;
+            }
             o.x = b[0] | ((unsigned)b[1] << 16); o.y = b[2] | ((unsigned)b[3] << 16);
             o.z = b[4] | ((unsigned)b[5] << 16); o.w = b[6] | ((unsigned)b[7] << 16);
         }
@@ -98,7 +104,7 @@ __global__ __launch_bounds__(256) void untile_y_kernel(const uint4* __restrict__
         const uint4 f = Y2[((long long)xt * KSpad + ks) * 64 + half * 32 + c];
         const unsigned wd[4] = {f.x, f.y, f.z, f.w};
         float v;
-        if (MODE == MODE_F32) v = __builtin_bit_cast(float, wd[e]);
+        if (MODE == MODE_F32) v = bitsf(wd[e]);
         else v = bf2f((unsigned short)((wd[e >> 1] >> (16 * (e & 1))) & 0xFFFFu));
         out[li + m * ld] = (double)v;
     }

@@ -220,7 +220,7 @@ static int launch_post(vbmf_ctx* c, int which, const float* In, int nslab) {
 
 static int launch_retile(vbmf_ctx* c, int which) {
     const Dims& d = which == 0 ? c->d1 : c->d2;
-    const float* Fac = which == 0 ? c->A32 : c->B32[c->bcur];
+    float* Fac = which == 0 ? c->A32 : c->B32[c->bcur];
     uint4* Ft = which == 0 ? c->FA : c->FB;
     const int grid = (d.XT + 3) / 4;
     DISPATCH_MODE(c->mode, DISPATCH_NH(c->NH, {
@@ -526,6 +526,9 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
         c->lds_limit = 64 * 1024 - 4096;
         (void)hipGetLastError();
     }
+    // the zero-fills above ran on the null stream; all later work runs on a non-blocking stream
+    // that does not order against it, so drain the device once here
+    if (hipDeviceSynchronize() != hipSuccess) { c->err = "hipDeviceSynchronize failed"; return bail(VBMF_ERR_HIP); }
     *out = c;
     return VBMF_OK;
 }
@@ -923,6 +926,34 @@ int vbmf_pass_bytes(vbmf_ctx* c, int pass, double* bytes) {
     const double LM = (double)c->L * (double)c->M;
     if (pass == 1) *bytes = LM * ybytes + (double)c->L * c->H * 4.0 + (double)c->M * c->H * 4.0;
     else *bytes = LM * ybytes + (double)c->M * c->H * 4.0 + (double)c->L * c->H * 4.0;
+    return VBMF_OK;
+}
+
+int vbmf_debug_peek(vbmf_ctx* c, int what, uint32_t* out, int64_t nwords, int64_t word_offset) {
+    if (!c || !out || nwords < 0 || word_offset < 0) return VBMF_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->o.device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (what == VBMF_PEEK_DIMS) {
+        const int v[16] = {c->Hp, c->NH, c->mode, c->d1.XT, c->d1.KS, c->d1.nsplit, c->d1.steps_per_split,
+                           c->d2.XT, c->d2.KS, c->d2.nsplit, c->d2.steps_per_split, c->kstep, c->npart, 0, 0, 0};
+        memcpy(out, v, sizeof(int) * (size_t)std::min<int64_t>(16, nwords));
+        return VBMF_OK;
+    }
+    const void* base = nullptr;
+    size_t words = 0;
+    switch (what) {
+        case VBMF_PEEK_P: base = c->P; words = (size_t)c->d1.nsplit * c->Hp * c->Mp; break;
+        case VBMF_PEEK_Q: base = c->Q; words = (size_t)c->d2.nsplit * c->Hp * c->Lp; break;
+        case VBMF_PEEK_A32: base = c->A32; words = (size_t)c->Mp * c->Hp; break;
+        case VBMF_PEEK_B32: base = c->B32[c->bcur]; words = (size_t)c->Lp * c->Hp; break;
+        case VBMF_PEEK_FA: base = c->FA; words = c->nFA * 4; break;
+        case VBMF_PEEK_FB: base = c->FB; words = c->nFB * 4; break;
+        case VBMF_PEEK_Y1: base = c->Y1; words = c->nY1 * 4; break;
+        case VBMF_PEEK_Y2: base = c->Y2; words = c->nY2 * 4; break;
+        default: FAIL(c, VBMF_ERR_INVALID, "vbmf_debug_peek: unknown buffer");
+    }
+    if ((size_t)(word_offset + nwords) > words) FAIL(c, VBMF_ERR_INVALID, "vbmf_debug_peek: range exceeds buffer (%zu words)", words);
+    HIPCHK(c, hipMemcpy(out, (const uint32_t*)base + word_offset, (size_t)nwords * 4, hipMemcpyDeviceToHost));
     return VBMF_OK;
 }
 
