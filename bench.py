@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- VB iterations/sec of the vbmf! sweep on MI355X (BASELINE.json metric).
+
+One "step" = one full sweep of vbmf! (src/vbmf.jl:193-214) with est_covs = est_var = true:
+updateA!, updateB!, updateCA!, updateCB!, updateSigma2!, the convergence scalar d and the ELBO, on
+synthetic toy_matrix data (examples/toy_data.jl:7-18) that is generated on the device and stays
+resident in HBM.  eps = 0, so the loop never exits early.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU, Y row-sharded (strong scaling: the SAME 100k x 10k problem), the M x H
+partial of Y'B and the packed Grams all-reduced with RCCL inside the library, on its compute stream.
+
+Prints ONE JSON line on rank 0.  `roofline` is for the streaming-contraction kernel (both passes of a
+sweep are launches of it): algorithmic bytes per launch / average launch duration, measured with HIP
+events recorded on the library's own stream during the timed region.  `cpu_baseline` times the fp64
+oracle in the reference's operation order (OpenBLAS, all host cores) on a bounded row-sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (L, M, H, y_dtype)  -- BASELINE.json configs[2] is the headline the metric is quoted on
+    "cfg3": (100000, 10000, 64, "bf16"),
+    "cfg2": (10000, 1000, 32, "f32"),
+    "cfg4": (1000000, 10000, 128, "bf16"),
+}
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
+    ap.add_argument("--L", type=int, default=0)
+    ap.add_argument("--M", type=int, default=0)
+    ap.add_argument("--H", type=int, default=0)
+    ap.add_argument("--ydtype", default="", choices=["", "bf16", "f32"])
+    ap.add_argument("--factor", default="auto", choices=["auto", "bf16", "bf16x2"])
+    ap.add_argument("--splits", type=int, default=0, help="split-K of the Y'B pass (0 = auto)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=25000, help="row sample of the CPU baseline")
+    ap.add_argument("--cpu-sweeps", type=int, default=3)
+    return ap.parse_args()
+
+
+def cpu_baseline(ctx, L, M, H, rows, sweeps, seed):
+    """fp64 oracle, reference operation order ("faithful": three GEMM passes over Y, the Y.^2 and 2Y'
+    temporaries and the M x M product of updateSigma2!), on the first `rows` rows of the SAME matrix."""
+    from oracle import vbmf_oracle as O          # checker/baseline only -- never on the product path
+    rows = int(min(rows, ctx.L))
+    Y = np.ascontiguousarray(ctx.get_Y(0, rows))
+    rng = np.random.default_rng(seed)
+    out = {}
+    for kind, fused in (("faithful", False), ("fused", True)):
+        p = O.vbmf_init(Y, H, ca=0.1, cb=0.1, sigma2=0.1, rng=np.random.default_rng(seed), materialize_yhat=False)
+        O.vbmf_(Y, p, 1, eps=0.0, est_covs=True, est_var=True, fused=fused)          # warm-up
+        ts = []
+        for _ in range(sweeps):
+            t0 = time.perf_counter()
+            O.vbmf_(Y, p, 1, eps=0.0, est_covs=True, est_var=True, fused=fused)
+            ts.append(time.perf_counter() - t0)
+        out[kind] = float(np.median(ts))
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([d.get("num_threads", 1) for d in threadpool_info()] or [os.cpu_count()])
+    except Exception:
+        threads = os.cpu_count()
+    scale = rows / float(L)
+    return {
+        "value": scale / out["faithful"], "unit": "sweeps/s", "cores": int(threads), "kind": "port",
+        "sample": f"first {rows} of {L} rows x {M} cols, H={H}, fp64 NumPy/OpenBLAS oracle in the reference's "
+                  f"operation order, median of {sweeps} sweeps = {out['faithful']:.3f} s, extrapolated linearly in L",
+        "fused_value": scale / out["fused"],
+        "sample_seconds_per_sweep": out["faithful"],
+    }
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        a.gpus = world
+
+    # torch first: the library then binds to the HIP/RCCL runtime torch already loaded (one runtime
+    # per process); torch is plumbing here (rendezvous, barrier, max-over-ranks), never compute
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__ as G
+    pkg = G.load_package()
+    capi = pkg.capi
+
+    L, M, H, ydt = CONFIGS[a.config]
+    L, M, H = a.L or L, a.M or M, a.H or H
+    ydt = a.ydtype or ydt
+    y_dtype = capi.VBMF_Y_F32 if ydt == "f32" else capi.VBMF_Y_BF16
+    f_dtype = {"auto": capi.VBMF_FACTOR_AUTO, "bf16": capi.VBMF_FACTOR_BF16, "bf16x2": capi.VBMF_FACTOR_BF16X2}[a.factor]
+    if ydt == "f32":
+        f_dtype = capi.VBMF_FACTOR_AUTO
+
+    # row shard of this rank (equal counts, remainder to the first shards: SURVEY 8e)
+    base, rem = divmod(L, world)
+    L_loc = base + (1 if rank < rem else 0)
+    row0 = rank * base + min(rank, rem)
+
+    ctx = capi.Context(L_loc, M, H, y_dtype=y_dtype, factor_dtype=f_dtype, device=local_rank, nranks=world,
+                       rank=rank, L_global=L, row_offset=row0, pass1_splits=a.splits)
+    if world > 1:
+        uid = [capi.Context.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init(uid[0])
+
+    ctx.set_Y_synthetic(20170101, H, 0.05)
+    rng = np.random.default_rng(20170102)
+    A0 = rng.standard_normal((M, H))
+    B0 = rng.standard_normal((L, H))[row0:row0 + L_loc]
+    z = np.zeros((H, H))
+    ctx.set_state(A0, B0, z, z, 0.1 * np.ones(H), 0.1 * np.ones(H), 0.1)
+    del A0, B0
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.sync()
+
+    if a.warmup > 0:
+        ctx.run(a.warmup, eps=0.0, est_covs=True, est_var=True)
+    ctx.profile_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    it, d, _ = ctx.run(a.steps, eps=0.0, est_covs=True, est_var=True)
+    barrier()
+    t1 = time.perf_counter()
+    prof = ctx.profile_read()
+    ctx.profile_enable(False)
+    assert it == a.steps, (it, a.steps)
+
+    elapsed = t1 - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    s = ctx.get_state(want_B=False)
+    bytes1, bytes2 = ctx.pass_bytes(1), ctx.pass_bytes(2)
+    n = prof["pass1_n"] + prof["pass2_n"]
+    avg_ms = (prof["pass1_ms"] + prof["pass2_ms"]) / max(n, 1)
+    avg_bytes = (bytes1 * prof["pass1_n"] + bytes2 * prof["pass2_n"]) / max(n, 1)
+    achieved = avg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    out = {
+        "metric": "VB iterations/sec",
+        "value": a.steps / elapsed,
+        "unit": "sweeps/s",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": 1e3 * elapsed / a.steps,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "bf16" if ydt == "bf16" else "f32",
+        "data": "synthetic",
+        "config": {"workload": f"vbmf! sweep, est_covs=est_var=true, {L}x{M} dense rank-{H}, toy_matrix data "
+                               f"(noise 0.05), Y {ydt} resident in HBM", "L": L, "M": M, "H": H,
+                   "y_dtype": ydt, "factor_operand": "f32" if ydt == "f32" else ("bf16" if a.factor == "bf16" else "bf16x2"),
+                   "accumulate": "fp32", "hxh_algebra": "fp64", "row_shards": world},
+        "roofline": {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "kernel": "stream_gemm_kernel (pass 1: Y'B, pass 2: Y*A; this rank's shard)",
+            "bytes_per_launch": avg_bytes, "avg_launch_ms": avg_ms, "launches": n,
+            "pass1": {"ms": prof["pass1_ms"] / max(prof["pass1_n"], 1), "bytes": bytes1,
+                      "GBps": bytes1 / max(prof["pass1_ms"] / max(prof["pass1_n"], 1), 1e-9) / 1e6},
+            "pass2": {"ms": prof["pass2_ms"] / max(prof["pass2_n"], 1), "bytes": bytes2,
+                      "GBps": bytes2 / max(prof["pass2_ms"] / max(prof["pass2_n"], 1), 1e-9) / 1e6},
+        },
+        "final": {"sigma2": s["sigma2"], "d": d},
+    }
+    if rank == 0 and not a.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(ctx, L, M, H, a.cpu_rows, a.cpu_sweeps, 20170102)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -116,7 +116,7 @@ def test_run_three_sweeps(pkg, mode, L, M, H):
     pg = to_pkg_params(pkg, po)
     pkg.vbmf_(Ys, pg, 3, eps=0.0, est_covs=True, est_var=True)
     _, n, d = O.vbmf_(Ys, po, 3, eps=0.0, est_covs=True, est_var=True)
-    tol3 = {k: 4 * v for k, v in tol.items()}
+    tol3 = {k: 6 * v for k, v in tol.items()}
     if mode == "bf16":
         # single-bf16 factors: ~3 significant digits in A/B; the noise variance (a cancellation of
         # O(||Y||^2) terms) is only meaningful with the hi+lo operand -- checked loosely here
@@ -156,7 +156,7 @@ def test_run_trajectory_well_conditioned(pkg, mode, L, M, H):
     assert max(errs[k] for k in ("A", "B", "ca", "cb")) < 20 * tol["default"], errs
     # Sigma = sigma2*inv(.) inherits sigma2's cancellation error
     assert max(errs[k] for k in ("SA", "SB", "s2")) < 20 * tol["sigma2"], errs
-    assert np.allclose(tr[:, 0], otr[:, 0], rtol=1e-2, atol=D_ATOL)
+    assert np.allclose(tr[:, 0], otr[:, 0], rtol=5e-3 if mode == "f32" else 3e-2, atol=D_ATOL)
     assert np.allclose(tr[:, 1], otr[:, 1], rtol=20 * tol["sigma2"])
     assert np.allclose(tr[:, 2], otr[:, 2], rtol=1e-3, atol=1.0)
 
