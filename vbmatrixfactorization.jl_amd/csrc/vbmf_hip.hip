@@ -66,6 +66,9 @@ struct vbmf_ctx {
     int64_t H1 = 0;
     bool has_mask = false;
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;       // H x H control kernels run here, overlapped with the streaming passes
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool pipelined = false;           // inside vbmf_run: control kernels go to `side`
     bool haveY = false, haveState = false;
     bool gA_valid = false, gB_valid = false, P_valid = false, kb_identity = false;
     double trYY_local = 0.0;
@@ -260,31 +263,54 @@ static int launch_gram(vbmf_ctx* c, int which, const float* cur, const float* pr
 
 static int ctrl_threads(int H) { return H <= 16 ? 64 : (H <= 32 ? 256 : 1024); }
 
+static hipStream_t ctrl_stream(vbmf_ctx* c) { return c->pipelined ? c->side : c->stream; }
+
+template <int R, int T>
+static void launch_cov_t(vbmf_ctx* c, int which, hipStream_t s) {
+    const size_t lds = (size_t)(5 * T * R) * sizeof(double);
+    const double N = which == 0 ? (double)c->Lg : (double)c->M;
+    hipLaunchKernelGGL((ctrl_cov_kernel<R, T>), dim3(1), dim3(T * T), lds, s, c->st, c->lay, (int)c->H, which, N,
+                       which == 0 ? c->SA32 : c->SB32, c->ints);
+}
+
 static int launch_ctrl_cov(vbmf_ctx* c, int which) {
     const int H = (int)c->H;
-    const size_t need = ((size_t)H * H + 2 * H) * sizeof(double);
-    const int use_lds = need <= (size_t)c->lds_limit;
-    const double N = which == 0 ? (double)c->Lg : (double)c->M;
-    hipLaunchKernelGGL(ctrl_cov_kernel, dim3(1), dim3(ctrl_threads(H)), use_lds ? need : 0, c->stream, c->st, c->lay, H,
-                       which, N, which == 0 ? c->SA32 : c->SB32, c->ints, use_lds);
+    hipStream_t s = ctrl_stream(c);
+    if (H <= 16) launch_cov_t<1, 16>(c, which, s);
+    else if (H <= 32) launch_cov_t<2, 16>(c, which, s);
+    else if (H <= 64) launch_cov_t<4, 16>(c, which, s);
+    else if (H <= 128) launch_cov_t<8, 16>(c, which, s);
+    else launch_cov_t<8, 32>(c, which, s);
     HIPCHK(c, hipGetLastError());
     return VBMF_OK;
 }
 
+template <int R>
+static void launch_eig_t(vbmf_ctx* c, int do_d, int do_b, hipStream_t s) {
+    constexpr int NP = 16 * R;
+    const size_t lds = (size_t)2 * NP * (NP + 1) * sizeof(float);
+    const int spectral = (c->o.reference_compat & VBMF_COMPAT_SPECTRAL_DELTA) ? 1 : 0;
+    hipLaunchKernelGGL((eig_kernel<R>), dim3(2), dim3(256), lds, s, c->st, c->lay, (int)c->H, spectral, do_d, do_b,
+                       c->ints);
+}
+
 static int launch_eig(vbmf_ctx* c, int do_d, int do_b) {
     const int H = (int)c->H;
-    const int n = (H + 1) & ~1;
-    const size_t need = ((size_t)n * n + n) * sizeof(double);
-    const int use_lds = need <= (size_t)c->lds_limit && n <= 256;
-    const int spectral = (c->o.reference_compat & VBMF_COMPAT_SPECTRAL_DELTA) ? 1 : 0;
-    hipLaunchKernelGGL(eig_kernel, dim3(2), dim3(ctrl_threads(H)), use_lds ? need : 0, c->stream, c->st, c->lay, H,
-                       spectral, do_d, do_b, c->ints, use_lds);
+    hipStream_t s = ctrl_stream(c);
+    if (H <= 16) launch_eig_t<1>(c, do_d, do_b, s);
+    else if (H <= 32) launch_eig_t<2>(c, do_d, do_b, s);
+    else if (H <= 64) launch_eig_t<4>(c, do_d, do_b, s);
+    else if (H <= 128) launch_eig_t<8>(c, do_d, do_b, s);
+    else {
+        const int spectral = (c->o.reference_compat & VBMF_COMPAT_SPECTRAL_DELTA) ? 1 : 0;
+        hipLaunchKernelGGL(eig_jacobi_kernel, dim3(2), dim3(1024), 0, s, c->st, c->lay, H, spectral, do_d, do_b, c->ints, 0);
+    }
     HIPCHK(c, hipGetLastError());
     return VBMF_OK;
 }
 
 static int launch_ctrl_end(vbmf_ctx* c, int flags, double eps, double* trace) {
-    hipLaunchKernelGGL(ctrl_end_kernel, dim3(1), dim3(256), 0, c->stream, c->st, c->lay, (int)c->H, (double)c->Lg,
+    hipLaunchKernelGGL(ctrl_end_kernel, dim3(1), dim3(256), 0, ctrl_stream(c), c->st, c->lay, (int)c->H, (double)c->Lg,
                        (double)c->M, flags, eps, trace, c->ints);
     HIPCHK(c, hipGetLastError());
     return VBMF_OK;
@@ -317,10 +343,16 @@ static int ensure_gram_B(vbmf_ctx* c) {
     return VBMF_OK;
 }
 
+// Ordering when pipelined (vbmf_run): control kernels are issued on `side`, everything that touches
+// L x H / M x H data on `stream`; ev[0] = SigmaA ready, ev[1] = A'A ready, ev[2] = SigmaB ready,
+// ev[3] = B Grams ready.  The streaming pass itself needs none of the control results, so it
+// overlaps the control kernels of the same half-sweep.
 static int do_update_A(vbmf_ctx* c) {
     TRY(ensure_gram_B(c));
     TRY(launch_ctrl_cov(c, 0));
+    if (c->pipelined) HIPCHK(c, hipEventRecord(c->ev[0], c->side));
     TRY(launch_stream(c, 0));
+    if (c->pipelined) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev[0], 0));
     if (c->o.nranks > 1) {
         const long long n = (long long)c->Hp * c->d1.XT * 32;
         hipLaunchKernelGGL(slab_sum_kernel, dim3(grid_for(n)), dim3(256), 0, c->stream, c->P, c->d1.nsplit, n, c->Pred, n,
@@ -332,6 +364,10 @@ static int do_update_A(vbmf_ctx* c) {
         TRY(launch_post(c, 0, c->P, c->d1.nsplit));
     }
     TRY(launch_gram(c, 0, c->A32, nullptr, true));
+    if (c->pipelined) {
+        HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->side, c->ev[1], 0));
+    }
     c->gA_valid = true;
     c->P_valid = true;
     c->kb_identity = false;
@@ -341,9 +377,15 @@ static int do_update_A(vbmf_ctx* c) {
 static int do_update_B(vbmf_ctx* c) {
     TRY(ensure_gram_A(c));
     TRY(launch_ctrl_cov(c, 1));
+    if (c->pipelined) HIPCHK(c, hipEventRecord(c->ev[2], c->side));
     TRY(launch_stream(c, 1));
+    if (c->pipelined) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev[2], 0));
     TRY(launch_post(c, 1, c->Q, c->d2.nsplit));
     TRY(launch_gram(c, 1, c->B32[c->bcur ^ 1], c->B32[c->bcur], true));
+    if (c->pipelined) {
+        HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->side, c->ev[3], 0));
+    }
     c->bcur ^= 1;
     c->gB_valid = true;
     c->P_valid = false;
@@ -425,6 +467,8 @@ int vbmf_destroy(vbmf_ctx* c) {
     for (void* b : bufs) if (b) hipFree(b);
     if (c->ints_host) hipHostFree(c->ints_host);
     if (c->scal_host) hipHostFree(c->scal_host);
+    for (auto& e : c->ev) if (e) hipEventDestroy(e);
+    if (c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
     return VBMF_OK;
@@ -519,13 +563,14 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
         hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         c->err = "pinned alloc / stream create failed"; return bail(VBMF_ERR_HIP);
     }
-    // large dynamic LDS for the H x H control kernels (160 KiB per CU on gfx950)
+    // large dynamic LDS (160 KiB per CU on gfx950) for the lambda_max kernel at 64 < H <= 128
     c->lds_limit = 160 * 1024 - 4096;
-    if (hipFuncSetAttribute((const void*)ctrl_cov_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit) != hipSuccess ||
-        hipFuncSetAttribute((const void*)eig_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit) != hipSuccess) {
-        c->lds_limit = 64 * 1024 - 4096;
-        (void)hipGetLastError();
+    if (hipFuncSetAttribute((const void*)eig_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit) != hipSuccess) {
+        c->err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"; return bail(VBMF_ERR_HIP);
     }
+    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) { c->err = "side stream create failed"; return bail(VBMF_ERR_HIP); }
+    for (auto& e : c->ev)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { c->err = "event create failed"; return bail(VBMF_ERR_HIP); }
     // the zero-fills above ran on the null stream; all later work runs on a non-blocking stream
     // that does not order against it, so drain the device once here
     if (hipDeviceSynchronize() != hipSuccess) { c->err = "hipDeviceSynchronize failed"; return bail(VBMF_ERR_HIP); }
@@ -798,6 +843,13 @@ int vbmf_run(vbmf_ctx* c, int64_t niter, double eps, int est_covs, int est_var, 
     }
     const int flags = (est_covs ? 3 : 0) | (est_var ? 4 : 0) | 8 | 16;
     const int bstart = c->bcur;
+    // from here on: control kernels on `side` (ordered after everything issued so far)
+    if (rc == VBMF_OK) {
+        hipError_t e = hipEventRecord(c->ev[3], c->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(c->side, c->ev[3], 0);
+        if (e != hipSuccess) { c->err = std::string("pipeline setup: ") + hipGetErrorString(e); rc = VBMF_ERR_HIP; }
+        c->pipelined = true;
+    }
     const int64_t check = 8;
     int64_t it = 0;
     bool stopped = false;
@@ -808,12 +860,17 @@ int vbmf_run(vbmf_ctx* c, int64_t niter, double eps, int est_covs, int est_var, 
         if (rc == VBMF_OK) rc = launch_ctrl_end(c, flags, eps, trace_dev);
         ++it;
         if (rc == VBMF_OK && (it % check == 0 || it == niter)) {
-            hipError_t e = hipMemcpyAsync(c->ints_host, c->ints, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+            // the loop test lives at the end of the side stream's ctrl_end
+            hipError_t e = hipMemcpyAsync(c->ints_host, c->ints, 4 * sizeof(int), hipMemcpyDeviceToHost, c->side);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->side);
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
             if (e != hipSuccess) { c->err = std::string("run loop sync: ") + hipGetErrorString(e); rc = VBMF_ERR_HIP; break; }
             if (c->ints_host[I_STOP] || c->ints_host[I_ERR]) stopped = true;
         }
     }
+    c->pipelined = false;
+    hipStreamSynchronize(c->side);
+    hipStreamSynchronize(c->stream);
     if (rc == VBMF_OK) {
         hipError_t e = hipMemcpyAsync(c->ints_host, c->ints, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(c->scal_host, c->st + c->lay.scal(), 32 * 8, hipMemcpyDeviceToHost, c->stream);
