@@ -1,0 +1,292 @@
+// stream_tune.hip -- developer harness: sweep variants of the streaming contraction kernel on random data.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I vbmatrixfactorization.jl_amd/csrc scripts/stream_tune.hip -o /tmp/stream_tune
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <string>
+#include "common.hpp"
+using namespace vbmf;
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+// generic variant: MODE (1=bf16, 2=bf16x2), NH, NXW, D, YAUX, FMODE (0 = normal, 1 = F always step 0 (L1-hot), 2 = no F loads)
+template <int MODE, int NH, int NXW_, int D, int YAUX, int FMODE, int WPB, int MINW>
+__global__ __launch_bounds__(WPB * 64, MINW) void k_stream(const uint4* __restrict__ Yt, const uint4* __restrict__ Ft, float* __restrict__ Out,
+                                                     int XG, int KS, int sps, int nsplit, long long ldOut) {
+    constexpr int NPART = (MODE == 2) ? 2 : 1;
+    constexpr int NF = NPART * NH;
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int bps = (XG + WPB - 1) / WPB;
+    int split, xb;
+    if ((nsplit & 7) == 0) { const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3; split = xcd + 8 * (q / bps); xb = q % bps; }
+    else { split = blockIdx.x / bps; xb = blockIdx.x % bps; }
+    const int xg = xb * WPB + wib;
+    if (xg >= XG || split >= nsplit) return;
+    const long long ks0 = (long long)split * sps;
+    __amdgpu_buffer_rsrc_t yr[NXW_];
+#pragma unroll
+    for (int i = 0; i < NXW_; ++i)
+        yr[i] = __builtin_amdgcn_make_buffer_rsrc((void*)(Yt + (((long long)(xg * NXW_ + i)) * KS + ks0) * 64), 0, (unsigned)sps * 1024u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc((void*)(Ft + ks0 * (NF * 64)), 0, (unsigned)sps * (NF * 1024u), 0x00020000);
+    const int voff = lane * 16;
+    f32x16 acc[NXW_][NH];
+#pragma unroll
+    for (int i = 0; i < NXW_; ++i)
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][h][r] = 0.f;
+    u32x4v yb[D][NXW_];
+    u32x4v fb[D][NF];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+#pragma unroll
+        for (int i = 0; i < NXW_; ++i) yb[d][i] = u32x4v{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int j = 0; j < NF; ++j) fb[d][j] = u32x4v{0u, 0u, 0u, 0u};
+    }
+    if (FMODE == 2) {
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+#pragma unroll
+            for (int j = 0; j < NF; ++j) fb[d][j] = __builtin_amdgcn_raw_buffer_load_b128(fr, voff, j * 1024, 0);
+    }
+    for (int s = -D; s < sps; s += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+#pragma unroll
+            for (int p = 0; p < NPART; ++p)
+#pragma unroll
+                for (int h = 0; h < NH; ++h) {
+                    const bf16x8 fa = __builtin_bit_cast(bf16x8, fb[d][p * NH + h]);
+#pragma unroll
+                    for (int i = 0; i < NXW_; ++i)
+                        acc[i][h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, __builtin_bit_cast(bf16x8, yb[d][i]), acc[i][h], 0, 0, 0);
+                }
+            const int sn = s + D + d;
+#pragma unroll
+            for (int i = 0; i < NXW_; ++i) yb[d][i] = __builtin_amdgcn_raw_buffer_load_b128(yr[i], voff, sn * 1024, YAUX);
+            if (FMODE != 2) {
+#pragma unroll
+                for (int j = 0; j < NF; ++j)
+                    fb[d][j] = __builtin_amdgcn_raw_buffer_load_b128(fr, voff, ((FMODE == 1 ? d : sn) * NF + j) * 1024, 0);
+            }
+            constexpr int NMFMA = NXW_ * NF;
+            __builtin_amdgcn_sched_group_barrier(0x008, NMFMA, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, NXW_ + (FMODE == 2 ? 0 : NF), 0);
+        }
+    }
+    const int c = lane & 31, half = lane >> 5;
+    float* o = Out + (long long)split * (NH * 32) * ldOut;
+#pragma unroll
+    for (int i = 0; i < NXW_; ++i) {
+        const long long x = (long long)(xg * NXW_ + i) * 32 + c;
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[(long long)(h * 32 + rho(r, half)) * ldOut + x] = acc[i][h][r];
+    }
+}
+
+// variant 2: separate ring depths for Y (HBM latency) and F (L2 latency); XCDMAP toggles the XCD-aware block map
+template <int NH, int NXW_, int DY, int DF, int WPB, int MINW, int XCDMAP>
+__global__ __launch_bounds__(WPB * 64, MINW) void k_stream2(const uint4* __restrict__ Yt, const uint4* __restrict__ Ft, float* __restrict__ Out,
+                                                      int XG, int KS, int sps, int nsplit, long long ldOut) {
+    constexpr int NF = 2 * NH;
+    static_assert(DY % DF == 0, "DY must be a multiple of DF");
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int bps = (XG + WPB - 1) / WPB;
+    int split, xb;
+    if (XCDMAP && (nsplit & 7) == 0) { const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3; split = xcd + 8 * (q / bps); xb = q % bps; }
+    else { split = blockIdx.x / bps; xb = blockIdx.x % bps; }
+    const int xg = xb * WPB + wib;
+    if (xg >= XG || split >= nsplit) return;
+    const long long ks0 = (long long)split * sps;
+    __amdgpu_buffer_rsrc_t yr[NXW_];
+#pragma unroll
+    for (int i = 0; i < NXW_; ++i)
+        yr[i] = __builtin_amdgcn_make_buffer_rsrc((void*)(Yt + (((long long)(xg * NXW_ + i)) * KS + ks0) * 64), 0, (unsigned)sps * 1024u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc((void*)(Ft + ks0 * (NF * 64)), 0, (unsigned)sps * (NF * 1024u), 0x00020000);
+    const int voff = lane * 16;
+    f32x16 acc[NXW_][NH];
+#pragma unroll
+    for (int i = 0; i < NXW_; ++i)
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][h][r] = 0.f;
+    u32x4v yb[DY][NXW_];
+    u32x4v fb[DF][NF];
+#pragma unroll
+    for (int d = 0; d < DY; ++d)
+#pragma unroll
+        for (int i = 0; i < NXW_; ++i) yb[d][i] = u32x4v{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int d = 0; d < DF; ++d)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) fb[d][j] = u32x4v{0u, 0u, 0u, 0u};
+    // lead-in: Y ring needs DY steps of run-ahead, F ring DF: start at -DY; F refills begin DF before their use
+    for (int s = -DY; s < sps; s += DY) {
+#pragma unroll
+        for (int d = 0; d < DY; ++d) {
+            constexpr int dummy = 0; (void)dummy;
+            const int fd = d % DF;
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int h = 0; h < NH; ++h) {
+                    const bf16x8 fa = __builtin_bit_cast(bf16x8, fb[fd][p * NH + h]);
+#pragma unroll
+                    for (int i = 0; i < NXW_; ++i)
+                        acc[i][h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, __builtin_bit_cast(bf16x8, yb[d][i]), acc[i][h], 0, 0, 0);
+                }
+#pragma unroll
+            for (int i = 0; i < NXW_; ++i) yb[d][i] = __builtin_amdgcn_raw_buffer_load_b128(yr[i], voff, (s + DY + d) * 1024, 2);
+#pragma unroll
+            for (int j = 0; j < NF; ++j)
+                fb[fd][j] = __builtin_amdgcn_raw_buffer_load_b128(fr, voff, ((s + d + DF) * NF + j) * 1024, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NXW_ * NF, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, NXW_ + NF, 0);
+        }
+    }
+    const int c = lane & 31, half = lane >> 5;
+    float* o = Out + (long long)split * (NH * 32) * ldOut;
+#pragma unroll
+    for (int i = 0; i < NXW_; ++i) {
+        const long long x = (long long)(xg * NXW_ + i) * 32 + c;
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[(long long)(h * 32 + rho(r, half)) * ldOut + x] = acc[i][h][r];
+    }
+}
+
+// pure read of the Y stream with the same access pattern (upper bound for the design)
+template <int NXW_, int D, int YAUX>
+__global__ __launch_bounds__(256) void k_read(const uint4* __restrict__ Yt, float* __restrict__ Out, int XG, int KS, int sps, int nsplit) {
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int bps = (XG + 3) / 4;
+    const int split = blockIdx.x / bps, xb = blockIdx.x % bps;
+    const int xg = xb * 4 + wib;
+    if (xg >= XG || split >= nsplit) return;
+    const long long ks0 = (long long)split * sps;
+    __amdgpu_buffer_rsrc_t yr[NXW_];
+#pragma unroll
+    for (int i = 0; i < NXW_; ++i)
+        yr[i] = __builtin_amdgcn_make_buffer_rsrc((void*)(Yt + (((long long)(xg * NXW_ + i)) * KS + ks0) * 64), 0, (unsigned)sps * 1024u, 0x00020000);
+    const int voff = lane * 16;
+    u32x4v acc = {0, 0, 0, 0};
+    for (int s = 0; s < sps; s += D) {
+        u32x4v t[D][NXW_];
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+#pragma unroll
+            for (int i = 0; i < NXW_; ++i) t[d][i] = __builtin_amdgcn_raw_buffer_load_b128(yr[i], voff, (s + d) * 1024, YAUX);
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+#pragma unroll
+            for (int i = 0; i < NXW_; ++i) acc ^= t[d][i];
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) Out[threadIdx.x] = 1.f;
+}
+
+struct Prob { long long X, K; int H; const char* name; };
+
+static void fill_random(uint4* d, size_t n) {
+    std::vector<unsigned> h(n * 4);
+    unsigned s = 12345u;
+    for (size_t i = 0; i < h.size(); ++i) {
+        s = s * 1664525u + 1013904223u;
+        // two bf16 in [-2,2): sign random, exponent 0x3E..0x3F, mantissa random
+        unsigned lo = ((s >> 3) & 0x807F) | (0x3F00 - (((s >> 20) & 1) << 8));
+        unsigned hi = ((s >> 11) & 0x807F) | (0x3F00 - (((s >> 21) & 1) << 8));
+        h[i] = lo | (hi << 16);
+    }
+    CK(hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+}
+
+template <class F>
+static double time_ms(F&& launch, int iters) {
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    launch(); launch();
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a));
+    for (int i = 0; i < iters; ++i) launch();
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    CK(hipGetLastError());
+    return ms / iters;
+}
+
+int main(int argc, char** argv) {
+    const int H = 64, NH = 2;
+    // pass 1: X = M = 10000, K = L = 100000;  pass 2: X = L, K = M
+    Prob probs[2] = {{10000, 100000, H, "pass1 (x=M=10k, k=L=100k)"}, {100000, 10000, H, "pass2 (x=L=100k, k=M=10k)"}};
+    for (int pi = 0; pi < 2; ++pi) {
+        const Prob& p = probs[pi];
+        const int XT = (int)((p.X + 255) / 256 * 8);
+        const long long ksmin = ((p.K + 63) / 64 * 64) / 16;
+        printf("== %s  XT=%d ksmin=%lld\n", p.name, XT, ksmin);
+        const double ybytes = (double)p.X * p.K * 2.0;
+        auto run = [&](auto kern, const char* tag, int NXW_, int WPB, int nsplit, int NFv) {
+            const int XG = XT / NXW_;
+            const int sps = (int)(((ksmin + nsplit - 1) / nsplit + 7) / 8 * 8);
+            const int KS = sps * nsplit;
+            uint4 *Y, *F; float* O;
+            const size_t nY = (size_t)XT * KS * 64 + 1024, nF = ((size_t)KS + 8) * NFv * 64;
+            CK(hipMalloc(&Y, nY * 16)); CK(hipMalloc(&F, nF * 16)); CK(hipMalloc(&O, (size_t)nsplit * H * XT * 32 * 4));
+            fill_random(Y, std::min<size_t>(nY, (size_t)1 << 24));       // random head, rest: copy blocks
+            for (size_t off = (size_t)1 << 24; off < nY; off += (size_t)1 << 24)
+                CK(hipMemcpy(Y + off, Y, std::min<size_t>((size_t)1 << 24, nY - off) * 16, hipMemcpyDeviceToDevice));
+            fill_random(F, nF);
+            const int bps = (XG + WPB - 1) / WPB;
+            const int grid = bps * nsplit;
+            const long long ld = (long long)XT * 32;
+            double ms = time_ms([&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(WPB * 64), 0, 0, Y, F, O, XG, KS, sps, nsplit, ld); }, 10);
+            printf("  %-44s nsplit=%3d grid=%5d waves=%6d  %.3f ms  %.0f GB/s (Y only)\n", tag, nsplit, grid, XG * nsplit, ms, ybytes / ms / 1e6);
+            CK(hipFree(Y)); CK(hipFree(F)); CK(hipFree(O));
+        };
+        const int ns_list1[] = {12, 13, 16, 24, 25, 26}, ns_list2[] = {1, 1, 1, 1, 1, 1};
+        const int* nsl = pi == 0 ? ns_list1 : ns_list2;
+        for (int q = 0; q < (pi == 0 ? 6 : 1); ++q) {
+            const int ns = nsl[q];
+            run(k_stream<2, NH, 4, 3, 2, 0, 4, 1>, "v1 NXW4 D3 (ref)", 4, 4, ns, 4);
+            run(k_stream2<NH, 4, 4, 2, 4, 1, 1>, "v2 NXW4 DY4 DF2 xcd", 4, 4, ns, 4);
+            run(k_stream2<NH, 4, 4, 2, 4, 1, 0>, "v2 NXW4 DY4 DF2 lin", 4, 4, ns, 4);
+            run(k_stream2<NH, 4, 6, 2, 4, 1, 0>, "v2 NXW4 DY6 DF2 lin", 4, 4, ns, 4);
+            run(k_stream2<NH, 4, 8, 2, 4, 1, 0>, "v2 NXW4 DY8 DF2 lin", 4, 4, ns, 4);
+            run(k_stream2<NH, 4, 12, 3, 4, 1, 0>, "v2 NXW4 DY12 DF3 lin", 4, 4, ns, 4);
+            run(k_stream2<NH, 4, 12, 3, 4, 1, 1>, "v2 NXW4 DY12 DF3 xcd", 4, 4, ns, 4);
+            run(k_stream2<NH, 4, 8, 2, 2, 1, 0>, "v2 NXW4 DY8 DF2 lin 128thr", 4, 2, ns, 4);
+            run(k_stream2<NH, 4, 8, 2, 8, 1, 0>, "v2 NXW4 DY8 DF2 lin 512thr", 4, 8, ns, 4);
+            run(k_stream2<NH, 2, 8, 2, 4, 1, 0>, "v2 NXW2 DY8 DF2 lin", 2, 4, ns, 4);
+            run(k_stream2<NH, 2, 12, 3, 4, 1, 0>, "v2 NXW2 DY12 DF3 lin", 2, 4, ns, 4);
+            run(k_stream2<NH, 8, 4, 2, 4, 1, 0>, "v2 NXW8 DY4 DF2 lin", 8, 4, ns, 4);
+            run(k_stream2<NH, 8, 6, 2, 4, 1, 0>, "v2 NXW8 DY6 DF2 lin", 8, 4, ns, 4);
+            run(k_stream2<NH, 8, 6, 2, 2, 1, 0>, "v2 NXW8 DY6 DF2 lin 128thr", 8, 2, ns, 4);
+        }
+        // pure read upper bound
+        {
+            const int nsplit = pi == 0 ? 16 : 1;
+            const int sps = (int)(((ksmin + nsplit - 1) / nsplit + 7) / 8 * 8);
+            const int KS = sps * nsplit;
+            uint4* Y; float* O;
+            const size_t nY = (size_t)XT * KS * 64 + 1024;
+            CK(hipMalloc(&Y, nY * 16)); CK(hipMalloc(&O, 4096));
+            CK(hipMemset(Y, 1, nY * 16));
+            const int XG = XT / 2, bps = (XG + 3) / 4;
+            double ms = time_ms([&] { hipLaunchKernelGGL((k_read<2, 4, 2>), dim3(bps * nsplit), dim3(256), 0, 0, Y, O, XG, KS, sps, nsplit); }, 10);
+            printf("  pure read NXW2 D4 nt: %.3f ms %.0f GB/s\n", ms, ybytes / ms / 1e6);
+            ms = time_ms([&] { hipLaunchKernelGGL((k_read<2, 8, 2>), dim3(bps * nsplit), dim3(256), 0, 0, Y, O, XG, KS, sps, nsplit); }, 10);
+            printf("  pure read NXW2 D8 nt: %.3f ms %.0f GB/s\n", ms, ybytes / ms / 1e6);
+            ms = time_ms([&] { hipLaunchKernelGGL((k_read<2, 8, 0>), dim3(bps * nsplit), dim3(256), 0, 0, Y, O, XG, KS, sps, nsplit); }, 10);
+            printf("  pure read NXW2 D8 default: %.3f ms %.0f GB/s\n", ms, ybytes / ms / 1e6);
+            CK(hipFree(Y)); CK(hipFree(O));
+        }
+    }
+    return 0;
+}

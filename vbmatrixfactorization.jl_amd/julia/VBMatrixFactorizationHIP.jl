@@ -1,0 +1,179 @@
+# VBMatrixFactorizationHIP.jl -- Julia host for the MI355X-native vbmf! path (ccall over include/vbmf_hip.h).
+#
+# Drop-in for the basic-VBMF surface of VBMatrixFactorization.jl (src/vbmf.jl): the same struct (field
+# names, order, Julia types), the same positional/keyword signatures.  Every numeric update runs in
+# libvbmf_hip.so (hand-written HIP for gfx950); there is no CPU fallback here.
+#
+# NOTE: this pipeline has no `julia` binary (neither the build container nor the GPU box), so this
+# file cannot be executed or tested here; its tested twin is the Python ctypes host
+# (vbmatrixfactorization.jl_amd/__init__.py), which binds the identical entry points.
+# Written for Julia >= 1.6 (the reference is Julia 0.5 syntax and does not parse on 1.x).
+module VBMatrixFactorizationHIP
+
+export vbmf_parameters, vbmf_init, vbmf, vbmf!, updateA!, updateB!, updateCA!, updateCB!, updateSigma2!, updateYHat!
+
+const libvbmf = get(ENV, "VBMF_HIP_LIB", joinpath(@__DIR__, "..", "libvbmf_hip.so"))
+
+# ---- the reference struct, src/vbmf.jl:22-40 (same field names, order and types) -----------------
+mutable struct vbmf_parameters
+    L::Int
+    M::Int
+    H::Int
+    H1::Int
+    labels::Array{Int64,1}
+    AHat::Array{Float64,2}
+    BHat::Array{Float64,2}
+    SigmaA::Array{Float64,2}
+    SigmaB::Array{Float64,2}
+    CA::Array{Float64,2}
+    CB::Array{Float64,2}
+    invCA::Array{Float64,2}
+    invCB::Array{Float64,2}
+    sigma2::Float64
+    YHat::Array{Float64,2}
+    vbmf_parameters() = new()
+end
+
+# ---- C ABI ------------------------------------------------------------------------------------------
+struct VbmfOpts            # must match vbmf_opts in include/vbmf_hip.h (56 bytes)
+    struct_size::Int32
+    device::Int32
+    y_dtype::Int32
+    factor_dtype::Int32
+    variant::Int32
+    reference_compat::UInt32
+    nranks::Int32
+    rank::Int32
+    L_global::Int64
+    row_offset::Int64
+    pass1_splits::Int32
+    reserved::Int32
+end
+
+const VBMF_Y_F32, VBMF_Y_BF16 = Int32(0), Int32(1)
+const STEP_A, STEP_B, STEP_CA, STEP_CB, STEP_SIGMA2 = 1, 2, 4, 8, 16
+
+mutable struct Ctx
+    h::Ptr{Cvoid}
+    Y::Array{Float64,2}       # keeps the identity of the uploaded Y
+end
+
+function chk(h::Ptr{Cvoid}, rc::Cint)
+    rc == 0 && return
+    msg = unsafe_string(ccall((:vbmf_last_error, libvbmf), Cstring, (Ptr{Cvoid},), h))
+    error("vbmf_hip error $rc: $msg")          # the reference signals errors with error(...), src/util.jl:116
+end
+
+const _cache = Dict{UInt,Ctx}()
+
+"One device context per Y array (uploaded once); y_dtype from ENV[\"VBMF_HIP_Y\"] = \"bf16\" | \"f32\"."
+function ctx_for(Y::Array{Float64,2}, H::Int)
+    key = hash((objectid(Y), size(Y), H))
+    haskey(_cache, key) && return _cache[key]
+    L, M = size(Y)
+    ydt = get(ENV, "VBMF_HIP_Y", "bf16") == "f32" ? VBMF_Y_F32 : VBMF_Y_BF16
+    opts = Ref(VbmfOpts(Int32(sizeof(VbmfOpts)), 0, ydt, 0, 0, 0xffffffff, 1, 0, 0, 0, 0, 0))
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = ccall((:vbmf_create, libvbmf), Cint, (Ref{Ptr{Cvoid}}, Int64, Int64, Int64, Ref{VbmfOpts}), h, L, M, H, opts)
+    chk(Ptr{Cvoid}(C_NULL), rc)
+    chk(h[], ccall((:vbmf_set_Y, libvbmf), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64), h[], Y, L))
+    c = Ctx(h[], Y)
+    finalizer(x -> ccall((:vbmf_destroy, libvbmf), Cint, (Ptr{Cvoid},), x.h), c)
+    _cache[key] = c
+    return c
+end
+
+function push!(c::Ctx, p::vbmf_parameters)
+    ca = [p.CA[h, h] for h in 1:p.H]; cb = [p.CB[h, h] for h in 1:p.H]
+    lab0 = p.labels .- 1                                   # C side is 0-based
+    chk(c.h, ccall((:vbmf_set_state, libvbmf), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Int64, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+         Float64, Ptr{Int64}, Int64, Int64),
+        c.h, p.AHat, p.M, p.BHat, p.L, p.SigmaA, p.SigmaB, ca, cb, p.sigma2, lab0, length(lab0), p.H1))
+end
+
+function pull!(c::Ctx, p::vbmf_parameters)
+    # the reference rebinds these fields with fresh arrays (src/vbmf.jl:96-98,110-112) ...
+    A = Array{Float64}(undef, p.M, p.H); B = Array{Float64}(undef, p.L, p.H)
+    SA = Array{Float64}(undef, p.H, p.H); SB = Array{Float64}(undef, p.H, p.H)
+    ca = Array{Float64}(undef, p.H); cb = Array{Float64}(undef, p.H); s2 = Ref{Float64}(0.0)
+    chk(c.h, ccall((:vbmf_get_state, libvbmf), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Int64, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Float64}),
+        c.h, A, p.M, B, p.L, SA, SB, ca, cb, s2))
+    p.AHat, p.BHat, p.SigmaA, p.SigmaB = A, B, SA, SB
+    for h in 1:p.H                                          # ... and writes CA/CB diagonals in place (:131,143)
+        p.CA[h, h] = ca[h]; p.CB[h, h] = cb[h]
+    end
+    p.invCA = inv(p.CA); p.invCB = inv(p.CB)
+    p.sigma2 = s2[]
+    return p
+end
+
+step!(Y, p, which) = (c = ctx_for(Y, p.H); push!(c, p); chk(c.h, ccall((:vbmf_step, libvbmf), Cint, (Ptr{Cvoid}, Cint), c.h, which)); pull!(c, p); nothing)
+
+# ---- the reference surface ---------------------------------------------------------------------------
+"src/vbmf.jl:48-73 (host side: the random draw is not part of the accelerated path)"
+function vbmf_init(Y::Array{Float64,2}, H::Int; ca::Float64 = 1.0, cb::Float64 = 1.0, sigma2::Float64 = 1.0,
+                   H1::Int = 0, labels::Array{Int64,1} = Array{Int64,1}())
+    params = vbmf_parameters()
+    L, M = size(Y)
+    params.L, params.M, params.H, params.H1, params.labels = L, M, H, H1, labels
+    params.AHat = randn(M, H)
+    params.AHat[labels, end-H1+1:end] .= 0.0
+    params.BHat = randn(L, H)
+    params.SigmaA = zeros(H, H); params.SigmaB = zeros(H, H)
+    Id = Matrix{Float64}(I_(H))
+    params.CA = ca * Id; params.CB = cb * Id
+    params.invCA = inv(params.CA); params.invCB = inv(params.CB)
+    params.sigma2 = sigma2
+    params.YHat = L * M <= (1 << 24) ? params.BHat * params.AHat' : Array{Float64}(undef, 0, 0)   # lazy above 16M elements
+    return params
+end
+I_(H) = [i == j ? 1.0 : 0.0 for i in 1:H, j in 1:H]
+
+"src/vbmf.jl:80-88 (shallow)"
+function Base.copy(params_in::vbmf_parameters)
+    params = vbmf_parameters()
+    for f in fieldnames(vbmf_parameters)
+        isdefined(params_in, f) && setfield!(params, f, getfield(params_in, f))
+    end
+    return params
+end
+
+updateA!(Y::Array{Float64,2}, params::vbmf_parameters) = step!(Y, params, STEP_A)            # src/vbmf.jl:95-102
+updateB!(Y::Array{Float64,2}, params::vbmf_parameters) = step!(Y, params, STEP_B)            # :109-113
+updateSigma2!(Y::Array{Float64,2}, params::vbmf_parameters) = step!(Y, params, STEP_SIGMA2)  # :153-157
+# the reference's updateCA!/updateCB!/updateYHat! take only params; here the Y selects the device context
+updateCA!(params::vbmf_parameters, Y::Array{Float64,2}) = step!(Y, params, STEP_CA)          # :129-134
+updateCB!(params::vbmf_parameters, Y::Array{Float64,2}) = step!(Y, params, STEP_CB)          # :141-146
+function updateYHat!(params::vbmf_parameters, Y::Array{Float64,2})                           # :120-122
+    c = ctx_for(Y, params.H); push!(c, params)
+    params.YHat = Array{Float64}(undef, params.L, params.M)
+    chk(c.h, ccall((:vbmf_get_YHat, libvbmf), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64), c.h, params.YHat, params.L))
+end
+
+"vbmf! -- src/vbmf.jl:175-231"
+function vbmf!(Y::Array{Float64,2}, params::vbmf_parameters, niter::Int; eps::Float64 = 1e-6, est_covs::Bool = false,
+               est_var::Bool = false, logdir = "", desc = "", verb = false)
+    logdir == "" || error("per-iteration JLD logging (src/data_manip.jl) is outside the accelerated path")
+    c = ctx_for(Y, params.H)
+    push!(c, params)
+    iters = Ref{Int64}(0); d = Ref{Float64}(0.0)
+    chk(c.h, ccall((:vbmf_run, libvbmf), Cint,
+        (Ptr{Cvoid}, Int64, Float64, Cint, Cint, Ref{Int64}, Ref{Float64}, Ptr{Float64}),
+        c.h, niter, eps, est_covs, est_var, iters, d, C_NULL))
+    pull!(c, params)
+    params.L * params.M <= (1 << 24) && updateYHat!(params, Y)                                # :217
+    verb && print("Factorization finished after ", iters[], " iterations, eps = ", d[], "\n")  # :221
+    return params
+end
+
+"vbmf -- src/vbmf.jl:238-248"
+function vbmf(Y::Array{Float64,2}, params_in::vbmf_parameters, niter::Int; kwargs...)
+    params = copy(params_in)
+    params.CA, params.CB = copy(params.CA), copy(params.CB)     # keep params_in reusable (see SURVEY App. A Q2)
+    vbmf!(Y, params, niter; kwargs...)
+    return params
+end
+
+end # module
