@@ -1,7 +1,8 @@
 """GPU parity tests: the HIP path (through the C ABI) against the fp64 oracle on identical inputs.
 
 Tolerances (stated per dtype; floating-point work, so not bit-exact):
-  f32 path   (Y fp32, exact-f32 MFMA, fp32 accumulate):   factors/covariances 2e-5 rel-Frobenius per update
+  f32 path   (Y fp32, exact-f32 MFMA, fp32 accumulate):   factors/covariances 5e-5 rel-Frobenius per update
+             (fp32 Gram rounding times the condition number of the H x H posterior precision)
   bf16x2     (Y bf16 as stored, factor hi+lo bf16):       1e-4 against the oracle fed the SAME stored Y
   bf16       (factor single bf16):                        5e-3
 The H x H algebra is fp64 on the device; sigma2 suffers the reference's own cancellation
@@ -25,7 +26,7 @@ def pkg():
     return G.load_package()
 
 
-TOL_F32 = dict(default=2e-5, sigma2=2e-4)
+TOL_F32 = dict(default=5e-5, sigma2=3e-4)
 TOL_X2 = dict(default=1e-4, sigma2=1e-3)
 TOL_BF16 = dict(default=1e-2, sigma2=5e-2)
 # d = ||B_old - B_new|| / ||B_old|| is a difference of fp32-stored factors: absolute noise floor

@@ -57,13 +57,13 @@ __device__ __forceinline__ float bf2f(unsigned short u) {
     return __builtin_bit_cast(float, ((unsigned)u) << 16);
 }
 
-// software-pipeline depth (k-steps in flight per wave) of the streaming kernel; every tiled buffer
-// is padded to a multiple of it and carries PIPE_D tiles of slack for the over-reading prefetch.
-constexpr int PIPE_D = 4;
-constexpr int NXW = 2;      // 32-wide output tiles per wave in the streaming kernel
+// padding quanta shared by every tiled buffer: k-step counts are multiples of PIPE_D (the streaming
+// kernel's ring depths divide it) and x-tile counts are multiples of XT_PAD (its per-wave tile count does)
+constexpr int PIPE_D = 12;
+constexpr int XT_PAD = 8;
 
 struct Dims {               // one streaming pass: Out[h][x] = sum_k F[k][h] * Y[k][x]
-    int XT;                 // 32-wide x tiles, multiple of NXW
+    int XT;                 // 32-wide x tiles, multiple of XT_PAD
     int KS;                 // k-steps, multiple of nsplit*PIPE_D
     int nsplit;             // split-K factor
     int steps_per_split;    // KS / nsplit, multiple of PIPE_D

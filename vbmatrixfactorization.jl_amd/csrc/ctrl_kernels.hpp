@@ -142,6 +142,7 @@ __global__ __launch_bounds__(T * T) void ctrl_cov_kernel(double* __restrict__ st
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ double red[16];
     if (ints[I_STOP]) return;
+    // (no s_setprio: A/B)
     constexpr int NP = T * R;
     const int Hp = lay.Hp;
     const int tx = threadIdx.x % T, ty = threadIdx.x / T;
@@ -210,6 +211,9 @@ __global__ __launch_bounds__(256) void eig_kernel(double* __restrict__ st, State
     __shared__ double red[16];
     __shared__ int s_arg;
     if (ints[I_STOP]) return;
+    // this workgroup shares the chip (often a CU) with the streaming pass it overlaps: its few waves sit
+    // on the sweep's dependency chain, the streaming waves do not -- take issue priority over them
+    // (no s_setprio: A/B)
     const int which = blockIdx.x;           // 0: GD, 1: GB
     if ((which == 0 && !do_d) || (which == 1 && !do_b)) return;
     const int Hp = lay.Hp;
@@ -223,14 +227,16 @@ __global__ __launch_bounds__(256) void eig_kernel(double* __restrict__ st, State
         if (threadIdx.x == 0) scal[slot] = tr;
         return;
     }
-    constexpr int T = 16, NP = T * R, LD = NP + 1;
+    // rows padded to LD = NP + 4 floats: 16-byte aligned row starts for ds_read_b128, and the 16 rows a
+    // wave reads side by side start 4 banks apart (conflict-free)
+    constexpr int T = 16, NP = T * R, LD = NP + 4;
     float* A0 = ldsf;
     float* A1 = ldsf + NP * LD;
     const int tx = threadIdx.x % T, ty = threadIdx.x / T;
     const float inv_tr = (float)(1.0 / tr);
     for (int t = threadIdx.x; t < NP * NP; t += blockDim.x) {
         const int i = t / NP, j = t - i * NP;
-        A0[i * LD + j] = (i < H && j < H) ? (float)(0.5 * (G[(long long)i * Hp + j] + G[(long long)j * Hp + i])) * inv_tr : 0.f;
+        A0[i * LD + j] = (i < H && j < H) ? (float)(G[(long long)i * Hp + j] * (double)inv_tr) : 0.f;
     }
     __syncthreads();
     float* cur = A0;
@@ -241,23 +247,28 @@ __global__ __launch_bounds__(256) void eig_kernel(double* __restrict__ st, State
         for (int a = 0; a < R; ++a)
 #pragma unroll
             for (int b = 0; b < R; ++b) c[a][b] = 0.f;
-        for (int k = 0; k < NP; ++k) {                       // C = T * T' (T symmetric): both operands are row reads
-            float ai[R], bj[R];
+        for (int k = 0; k < NP; k += 4) {                    // C = T * T' (T symmetric): both operands are row reads
+            float4 ai[R], bj[R];
 #pragma unroll
-            for (int a = 0; a < R; ++a) ai[a] = cur[(ty + T * a) * LD + k];
+            for (int a = 0; a < R; ++a) ai[a] = *reinterpret_cast<const float4*>(cur + (ty + T * a) * LD + k);
 #pragma unroll
-            for (int b = 0; b < R; ++b) bj[b] = cur[(tx + T * b) * LD + k];
+            for (int b = 0; b < R; ++b) bj[b] = *reinterpret_cast<const float4*>(cur + (tx + T * b) * LD + k);
 #pragma unroll
             for (int a = 0; a < R; ++a)
 #pragma unroll
-                for (int b = 0; b < R; ++b) c[a][b] = fmaf(ai[a], bj[b], c[a][b]);
+                for (int b = 0; b < R; ++b) {
+                    c[a][b] = fmaf(ai[a].x, bj[b].x, c[a][b]);
+                    c[a][b] = fmaf(ai[a].y, bj[b].y, c[a][b]);
+                    c[a][b] = fmaf(ai[a].z, bj[b].z, c[a][b]);
+                    c[a][b] = fmaf(ai[a].w, bj[b].w, c[a][b]);
+                }
         }
         double ss = 0.0;
 #pragma unroll
         for (int a = 0; a < R; ++a)
 #pragma unroll
             for (int b = 0; b < R; ++b) ss += (double)c[a][b] * (double)c[a][b];
-        ss = block_sum(ss, red);
+        ss = block_sum(ss, red);                             // ||T^2||_F^2 with ||T||_F = 1: -> 1 iff T is a rank-1 projector
         const float sc = (ss > 0.0) ? (float)(1.0 / sqrt(ss)) : 0.f;
 #pragma unroll
         for (int a = 0; a < R; ++a)
@@ -265,6 +276,7 @@ __global__ __launch_bounds__(256) void eig_kernel(double* __restrict__ st, State
             for (int b = 0; b < R; ++b) nxt[(ty + T * a) * LD + tx + T * b] = c[a][b] * sc;
         __syncthreads();
         float* tmp = cur; cur = nxt; nxt = tmp;
+        if (sq > 0 && fabs(ss - 1.0) < 1e-7) break;          // uniform: converged to the dominant projector
     }
     // dominant column = the one with the largest diagonal entry of the (near) projector
     if (threadIdx.x < 64) {
@@ -277,30 +289,26 @@ __global__ __launch_bounds__(256) void eig_kernel(double* __restrict__ st, State
         if (threadIdx.x == 0) s_arg = arg;
     }
     __syncthreads();
-    // fp64 polish on the original matrix: v <- G v (twice), lambda = v'Gv / v'v
-    double* v0 = reinterpret_cast<double*>(nxt);            // reuse the idle LDS buffer (>= 2*NP doubles)
-    double* v1 = v0 + NP;
-    for (int i = threadIdx.x; i < H; i += blockDim.x) v0[i] = (double)cur[i * LD + s_arg];
-    __syncthreads();
-    double lam = 0.0;
-    for (int it = 0; it < 3; ++it) {
-        double num = 0.0, den = 0.0;
-        for (int i = threadIdx.x; i < H; i += blockDim.x) {
-            double acc = 0.0;
-            for (int j = 0; j < H; ++j) acc += 0.5 * (G[(long long)i * Hp + j] + G[(long long)j * Hp + i]) * v0[j];
-            v1[i] = acc;
-            num += v0[i] * acc;
-            den += v0[i] * v0[i];
+    // lambda = v'Gv / v'v in fp64 on the ORIGINAL matrix (error quadratic in v's error).  4 threads per
+    // row, each a contiguous quarter of it.
+    double num = 0.0, den = 0.0;
+    {
+        const int i = threadIdx.x >> 2, q = threadIdx.x & 3;
+        for (int i0 = 0; i0 < H; i0 += 64) {
+            const int row = i0 + i;
+            if (row < H) {
+                const int jn = (H + 3) / 4, j0 = q * jn, j1 = min(H, j0 + jn);
+                double acc = 0.0;
+                for (int j = j0; j < j1; ++j) acc += G[(long long)row * Hp + j] * (double)cur[j * LD + s_arg];
+                const double vi = (double)cur[row * LD + s_arg];
+                num += vi * acc;
+                if (q == 0) den += vi * vi;
+            }
         }
-        num = block_sum(num, red);
-        den = block_sum(den, red);
-        lam = den > 0.0 ? num / den : 0.0;
-        const double sc = den > 0.0 ? 1.0 / sqrt(den) : 0.0;
-        __syncthreads();
-        for (int i = threadIdx.x; i < H; i += blockDim.x) v0[i] = v1[i] * sc;
-        __syncthreads();
     }
-    if (threadIdx.x == 0) scal[slot] = lam;
+    num = block_sum(num, red);
+    den = block_sum(den, red);
+    if (threadIdx.x == 0) scal[slot] = den > 0.0 ? num / den : 0.0;
 }
 
 // Fallback for H > 128 (matrix does not fit the squaring kernel's LDS tiles): cyclic Jacobi with
@@ -402,6 +410,7 @@ __global__ __launch_bounds__(256) void ctrl_end_kernel(double* __restrict__ st, 
                                                        double* __restrict__ trace, int* __restrict__ ints) {
     __shared__ double red[16];
     if (ints[I_STOP]) return;
+    // (no s_setprio: A/B)
     const int Hp = lay.Hp;
     const double* GA = st + lay.GA();
     const double* GB = st + lay.GB();

@@ -200,16 +200,25 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restric
     out[j] = s;
 }
 
-// out[i] = sum_s slabs[s][i]   (fp32, fixed order => deterministic)
+// out[i] = sum_s slabs[s][i]   (fp32, fixed order => deterministic).  16-byte loads, whole-chip grid:
+// the split-K partials of the Y'B pass (nsplit x 2.5 MB at 10k x 64) are folded here at HBM/L2 rate
+// instead of inside the 80-block post kernel.  n must be a multiple of 4 (it is: Hp * Xp).
 __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slabs, int nslab,
                                                        long long slabStride, float* __restrict__ out, long long n,
                                                        const int* __restrict__ stop) {
     if (stop && *stop) return;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+    const long long n4 = n >> 2;
+    const float4* in4 = reinterpret_cast<const float4*>(slabs);
+    float4* out4 = reinterpret_cast<float4*>(out);
+    const long long stride4 = slabStride >> 2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
          i += (long long)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int k = 0; k < nslab; ++k) s += slabs[(long long)k * slabStride + i];
-        out[i] = s;
+        float4 s = in4[i];
+        for (int k = 1; k < nslab; ++k) {
+            const float4 v = in4[(long long)k * stride4 + i];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        out4[i] = s;
     }
 }
 

@@ -7,21 +7,29 @@
 //
 // Design (MI355X): the pass is HBM-bound (bf16 Y: 2H flop per 2 bytes = 64 flop/B at H=64 against a
 // machine balance of ~300), so the kernel is built as a pure stream:
-//   * Y is read exactly once, from its pre-tiled copy, with 1 KiB fully-coalesced wave loads
+//   * Y is read exactly once, from its pre-tiled copy, with 1 KiB fully-coalesced wave loads (nt)
 //     straight into VGPRs -- each fragment is used by one wave only, so an LDS round trip would be
 //     pure overhead.  Waves are independent: no LDS, no barriers, nothing to drain.
 //   * The factor operand (H x k-step, L2-resident) is read as pre-tiled MFMA A-fragments; in the
 //     bf16x2 mode as a hi and a lo bf16 fragment (two MFMAs) so that only Y's own storage rounding
-//     remains -- the MFMA pipe has ~4x headroom at H=64.
-//   * A register ring of PIPE_D k-steps keeps >= 8 KiB of Y per wave in flight (64+ KiB per CU at
-//     8 waves/CU), refilled immediately after each slot is consumed; the prefetch over-reads up to
-//     PIPE_D tiles past the split (buffers carry that slack) so no load sits under a branch.
+//     remains -- the MFMA pipe has ~4x headroom at H=64.  Its L2->L1 traffic is what costs
+//     bandwidth (measured: 4.2 -> 5.7 TB/s when it is removed), so a wave covers NXW = 8/NH
+//     32-wide x tiles per factor fragment (128 accumulator registers).
+//   * Two register rings, refilled in place right after use: DY k-steps of Y (HBM latency; a CU's
+//     throughput is bytes-in-flight / latency, measured ~30 GB/s at 48 KiB) and DF k-steps of the
+//     factor (L2 latency).  The rings start as zeros and the loop runs DY lead-in steps on them, so
+//     the only load order the waitcnt pass sees is the loop's own and every wait is a counted vmcnt.
+//   * Loads are SGPR-descriptor buffer loads (descriptor = the wave's stream, SGPR step offset, VGPR
+//     lane*16): unlike plain loads, which hipcc folds back into a load-at-use (phi-of-loads ->
+//     load-of-phi), the intrinsic keeps the rings in flight.  Run-ahead past a split reads the next
+//     tiles / the buffers' slack and is discarded.
 //   * Output tile: MFMA A operand = factor (rows h), B operand = Y (columns x), so every accumulator
 //     register is 32 consecutive x of one h row -> two 128-byte segments per store instruction.
 //   * Split-K partials go to per-split slabs with plain stores (deterministic; the consumer sums them
 //     while it loads), not atomics.
-//   * blockIdx -> (split, x-group) keeps the blocks that share an XCD (b % 8) on the same split, so a
-//     split's factor fragments are fetched into that XCD's L2 once.
+//   * Grid: per-CU throughput is latency-bound, so time = the most loaded CU: the planner (host) picks
+//     the split factor that makes the block count one balanced wave over the 256 CUs
+//     (measured at 100k x 10k: 240 blocks 5.7 TB/s, 260 blocks 3.3 TB/s).
 #pragma once
 #include "common.hpp"
 
@@ -30,7 +38,7 @@ namespace vbmf {
 // cache policy of the Y stream: 2 = nt (streamed once); 0 = default
 constexpr int Y_AUX = 2;
 
-template <int MODE, int NH, int NXW_, int D>
+template <int MODE, int NH, int NXW_, int DY, int DF>
 __global__ __launch_bounds__(256) void stream_gemm_kernel(const uint4* __restrict__ Yt,   // [XT][KS][64]
                                                           const uint4* __restrict__ Ft,   // [KS][NPART][NH][64]
                                                           float* __restrict__ Out,        // [nsplit][NH*32][ldOut]
@@ -38,28 +46,17 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const uint4* __restric
                                                           long long ldOut, const int* __restrict__ stop) {
     constexpr int NPART = ModeTraits<MODE>::NPART;
     constexpr int NF = NPART * NH;
-    static_assert(PIPE_D % D == 0, "ring depth must divide the padding quantum");
+    static_assert(PIPE_D % DY == 0 && DY % DF == 0, "ring depths must divide the padding quantum");
+    static_assert(XT_PAD % NXW_ == 0, "tiles per wave must divide the x padding quantum");
     if (stop && *stop) return;
 
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform => SGPR addressing
     const int bps = (XG + 3) >> 2;                       // blocks per split
-    int split, xb;
-    if ((nsplit & 7) == 0) {                              // XCD-aware: blocks b, b+8, ... share an XCD
-        const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-        split = xcd + 8 * (q / bps);
-        xb = q % bps;
-    } else {
-        split = blockIdx.x / bps;
-        xb = blockIdx.x % bps;
-    }
-    const int xg = xb * 4 + wib;
+    const int split = blockIdx.x / bps;
+    const int xg = (blockIdx.x % bps) * 4 + wib;
     if (xg >= XG || split >= nsplit) return;              // wave-uniform
 
-    // One buffer descriptor per stream, covering exactly this wave's k-range: loads are addressed
-    // as (SGPR descriptor, SGPR step offset, VGPR lane*16), the ring's over-read past the range is
-    // clamped to zero by the hardware bounds check, and -- unlike plain loads, which hipcc folds back
-    // into a load-at-use (phi-of-loads -> load-of-phi) -- the intrinsic keeps the ring in flight.
     const long long ks0 = (long long)split * steps_per_split;
     const unsigned ybytes = (unsigned)steps_per_split * 1024u;
     const unsigned fbytes = (unsigned)steps_per_split * (NF * 1024u);
@@ -80,29 +77,27 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const uint4* __restric
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][h][r] = 0.f;
 
-    // The ring starts as zeros and the loop runs one extra leading iteration (s = -D) whose MFMAs
-    // multiply zeros while its refills fetch steps 0..D-1.  With no separate prologue the only
-    // load order the waitcnt pass sees is the loop's own, so every in-loop wait is the counted
-    // vmcnt((D-1)*(NXW+NF)) family -- a hand-ordered prologue gets re-ordered by instruction
-    // selection and forces a near-drain wait inside the loop.
-    u32x4v yb[D][NXW_];
-    u32x4v fb[D][NF];
+    u32x4v yb[DY][NXW_];
+    u32x4v fb[DF][NF];
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
+    for (int d = 0; d < DY; ++d)
 #pragma unroll
         for (int i = 0; i < NXW_; ++i) yb[d][i] = u32x4v{0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int j = 0; j < NF; ++j) fb[d][j] = u32x4v{0u, 0u, 0u, 0u};
-    }
-
-    for (int s = -D; s < steps_per_split; s += D) {
+    for (int d = 0; d < DF; ++d)
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            // consume ring slot d ...
+        for (int j = 0; j < NF; ++j) fb[d][j] = u32x4v{0u, 0u, 0u, 0u};
+
+    for (int s = -DY; s < steps_per_split; s += DY) {
+#pragma unroll
+        for (int d = 0; d < DY; ++d) {
+            constexpr int UNUSED = 0; (void)UNUSED;
+            const int fd = d % DF;
+            // consume Y slot d and factor slot d % DF (lead-in iterations multiply zeros) ...
             if constexpr (MODE == MODE_F32) {
 #pragma unroll
                 for (int h = 0; h < NH; ++h) {
-                    const f32x4 fe = __builtin_bit_cast(f32x4, fb[d][h]);
+                    const f32x4 fe = __builtin_bit_cast(f32x4, fb[fd][h]);
 #pragma unroll
                     for (int i = 0; i < NXW_; ++i) {
                         const f32x4 ye = __builtin_bit_cast(f32x4, yb[d][i]);
@@ -116,24 +111,27 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const uint4* __restric
                 for (int p = 0; p < NPART; ++p)
 #pragma unroll
                     for (int h = 0; h < NH; ++h) {
-                        const bf16x8 fa = __builtin_bit_cast(bf16x8, fb[d][p * NH + h]);
+                        const bf16x8 fa = __builtin_bit_cast(bf16x8, fb[fd][p * NH + h]);
 #pragma unroll
                         for (int i = 0; i < NXW_; ++i)
                             acc[i][h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                                 fa, __builtin_bit_cast(bf16x8, yb[d][i]), acc[i][h], 0, 0, 0);
                     }
             }
-            // ... and refill it at once with step s+D+d (past the split the descriptor returns zeros).
-            // MFMAs read their operands at issue and the wave issues in order, so the refill may
-            // target the very registers the MFMAs above just consumed.
-            const int sn = s + D + d;
+            // ... and refill both at once (Y: step +DY, factor: step +DF).  MFMAs read their operands at
+            // issue and a wave issues in order, so the refill may target the registers just consumed.
+            // The lead-in's factor steps are clamped to step 0 (finite data times the zero Y ring); the
+            // run-ahead past the split lands in the next split's tiles or in the buffers' PIPE_D tiles of
+            // slack and is never consumed.  Nothing here relies on the descriptor's bounds check (the SGPR
+            // offset is not part of it).
 #pragma unroll
-            for (int i = 0; i < NXW_; ++i) yb[d][i] = __builtin_amdgcn_raw_buffer_load_b128(yr[i], voff, sn * 1024, Y_AUX);
+            for (int i = 0; i < NXW_; ++i)
+                yb[d][i] = __builtin_amdgcn_raw_buffer_load_b128(yr[i], voff, (s + DY + d) * 1024, Y_AUX);
 #pragma unroll
             for (int j = 0; j < NF; ++j)
-                fb[d][j] = __builtin_amdgcn_raw_buffer_load_b128(fr, voff, (sn * NF + j) * 1024, 0);
-            // pin that order in the emitted stream (otherwise hipcc sinks every refill to the loop
-            // bottom and drains vmcnt(0) each iteration)
+                fb[fd][j] = __builtin_amdgcn_raw_buffer_load_b128(fr, voff, (max(s + d + DF, 0) * NF + j) * 1024, 0);
+            // pin that order in the emitted stream (otherwise hipcc sinks every refill to the loop bottom
+            // and drains vmcnt(0) each iteration)
             constexpr int NMFMA = NXW_ * NF * (MODE == MODE_F32 ? 4 : 1);
             __builtin_amdgcn_sched_group_barrier(0x008, NMFMA, 0);
             __builtin_amdgcn_sched_group_barrier(0x020, NXW_ + NF, 0);

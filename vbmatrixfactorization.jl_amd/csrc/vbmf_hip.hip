@@ -133,25 +133,48 @@ static inline int grid_for(int64_t n, int block = 256, int cap = 8192) {
     return (int)std::max<int64_t>(1, std::min<int64_t>((n + block - 1) / block, cap));
 }
 
-// per-NH geometry of the streaming kernel (register budget: acc = NXW*NH*16, ring = D*(NXW+NF)*4)
-template <int NH> struct StreamCfg { static constexpr int NXWc = 2; static constexpr int Dc = 4; };
-template <> struct StreamCfg<4> { static constexpr int NXWc = 2; static constexpr int Dc = 2; };
-template <> struct StreamCfg<8> { static constexpr int NXWc = 1; static constexpr int Dc = 2; };
+// per-NH geometry of the streaming kernel: NXW * NH = 8 accumulator tiles (128 registers) per wave,
+// Y ring DY and factor ring DF k-steps deep (register budget: 128 + 4*(DY*NXW + DF*NF) + addressing)
+template <int NH> struct StreamCfg;
+template <> struct StreamCfg<1> { static constexpr int NXWc = 8; static constexpr int DYc = 3; static constexpr int DFc = 3; };
+template <> struct StreamCfg<2> { static constexpr int NXWc = 4; static constexpr int DYc = 6; static constexpr int DFc = 2; };
+template <> struct StreamCfg<4> { static constexpr int NXWc = 2; static constexpr int DYc = 6; static constexpr int DFc = 2; };
+template <> struct StreamCfg<8> { static constexpr int NXWc = 1; static constexpr int DYc = 4; static constexpr int DFc = 1; };
 
-static int nxw_of(int NH) { return NH == 8 ? 1 : 2; }
+static int nxw_of(int NH) { return 8 / NH; }
+// The main stream is CU-masked to 240 of the 256 CUs (30 per XCD); the remaining 2 per XCD belong to the
+// side stream so the H x H control kernels never share a CU with a streaming block (measured: sharing
+// stretches the streaming pass by the control chain's length because the pass ends with its slowest CU).
+constexpr int NUM_CU = 240;
+constexpr int SIDE_CU = 16;
 
-static void plan_pass(Dims& d, int64_t X, int64_t K, int kstep, int NH, int want_splits) {
-    d.XT = (int)rup(cdiv(X, 32), NXW);
-    const int64_t ks_min = rup(cdiv(rup(K, 32 * NXW), kstep), PIPE_D);   // K padded like the other pass's x tiles
+// Split-K plan.  A CU's streaming rate is latency-bound (bytes in flight / latency; measured ~30 GB/s
+// per CU for this kernel, i.e. ~190 busy CUs already saturate HBM), so a pass takes
+//     max( rounds * bytes_per_block / R_CU ,  total_bytes / R_HBM )  +  slab write+read
+// with rounds = ceil(blocks / 256).  Pick the split factor minimising that (measured at 100k x 10k:
+// 240 blocks 0.35 ms, 260 blocks 0.61 ms, 160 blocks 0.44 ms -- the model's ordering).
+static void plan_pass(Dims& d, int64_t X, int64_t K, int kstep, int NH, int Hp, double ybytes, int want_splits) {
+    d.XT = (int)rup(cdiv(X, 32), XT_PAD);
+    const int64_t ks_min = rup(cdiv(rup(K, 32 * XT_PAD), kstep), PIPE_D);   // K padded like the other pass's x tiles
     const int XG = d.XT / nxw_of(NH);
+    const int bps = (XG + 3) / 4;
     int ns = want_splits;
-    if (ns <= 0) {                                                    // aim at ~2300 waves (9 per CU)
-        ns = (int)std::max<int64_t>(1, (2304 + XG / 2) / std::max(1, XG));
-        ns = std::min(ns, 64);
+    if (ns <= 0) {
+        const double R_CU = 30e9, R_HBM = 5.9e12;
+        const double total = (double)d.XT * 32.0 * (double)ks_min * kstep * ybytes;
+        const double out_bytes = (double)Hp * d.XT * 32.0 * 4.0;
+        const int ns_max = (int)std::max<int64_t>(1, std::min<int64_t>(64, ks_min / (2 * PIPE_D)));
+        double best = 1e300;
+        ns = 1;
+        for (int cand = 1; cand <= ns_max; ++cand) {
+            const int blocks = bps * cand;
+            const int rounds = (blocks + NUM_CU - 1) / NUM_CU;
+            const double t = std::max(rounds * (total / blocks) / R_CU, total / R_HBM) + cand * out_bytes * 2.0 / R_HBM;
+            if (t < best * 0.999) { best = t; ns = cand; }
+        }
     }
-    ns = (int)std::max<int64_t>(1, std::min<int64_t>(ns, ks_min / (2 * PIPE_D)));   // >= 8 steps per split
-    if (ns >= 8) ns = ns / 8 * 8;                                     // XCD-aware mapping wants % 8
-    d.nsplit = std::max(1, ns);
+    ns = (int)std::max<int64_t>(1, std::min<int64_t>(ns, std::max<int64_t>(1, ks_min / PIPE_D)));
+    d.nsplit = ns;
     d.steps_per_split = (int)rup(cdiv(ks_min, d.nsplit), PIPE_D);
     d.KS = d.steps_per_split * d.nsplit;
 }
@@ -195,7 +218,7 @@ static int launch_stream(vbmf_ctx* c, int pass) {
     prof_begin(c, pass);
     DISPATCH_MODE(c->mode, DISPATCH_NH(c->NH, {
         using Cfg = StreamCfg<NHc>;
-        hipLaunchKernelGGL((stream_gemm_kernel<MODEc, NHc, Cfg::NXWc, Cfg::Dc>), dim3(grid), dim3(256), 0, c->stream,
+        hipLaunchKernelGGL((stream_gemm_kernel<MODEc, NHc, Cfg::NXWc, Cfg::DYc, Cfg::DFc>), dim3(grid), dim3(256), 0, c->stream,
                            Y, F, out, XG, d.KS, d.steps_per_split, d.nsplit, ld, c->ints + I_STOP);
     }));
     prof_end(c);
@@ -288,7 +311,7 @@ static int launch_ctrl_cov(vbmf_ctx* c, int which) {
 template <int R>
 static void launch_eig_t(vbmf_ctx* c, int do_d, int do_b, hipStream_t s) {
     constexpr int NP = 16 * R;
-    const size_t lds = (size_t)2 * NP * (NP + 1) * sizeof(float);
+    const size_t lds = (size_t)2 * NP * (NP + 4) * sizeof(float);
     const int spectral = (c->o.reference_compat & VBMF_COMPAT_SPECTRAL_DELTA) ? 1 : 0;
     hipLaunchKernelGGL((eig_kernel<R>), dim3(2), dim3(256), lds, s, c->st, c->lay, (int)c->H, spectral, do_d, do_b,
                        c->ints);
@@ -353,15 +376,16 @@ static int do_update_A(vbmf_ctx* c) {
     if (c->pipelined) HIPCHK(c, hipEventRecord(c->ev[0], c->side));
     TRY(launch_stream(c, 0));
     if (c->pipelined) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev[0], 0));
-    if (c->o.nranks > 1) {
+    if (c->o.nranks > 1 || c->d1.nsplit > 1) {
         const long long n = (long long)c->Hp * c->d1.XT * 32;
-        hipLaunchKernelGGL(slab_sum_kernel, dim3(grid_for(n)), dim3(256), 0, c->stream, c->P, c->d1.nsplit, n, c->Pred, n,
-                           c->ints + I_STOP);
+        hipLaunchKernelGGL(slab_sum_kernel, dim3(grid_for(n / 4, 256, 2048)), dim3(256), 0, c->stream, c->P, c->d1.nsplit, n,
+                           c->Pred, n, c->ints + I_STOP);
         HIPCHK(c, hipGetLastError());
-        NCCLCHK(c, ncclAllReduce(c->Pred, c->Pred, (size_t)n, ncclFloat, ncclSum, c->comm, c->stream));
+        if (c->o.nranks > 1)
+            NCCLCHK(c, ncclAllReduce(c->Pred, c->Pred, (size_t)n, ncclFloat, ncclSum, c->comm, c->stream));
         TRY(launch_post(c, 0, c->Pred, 1));
     } else {
-        TRY(launch_post(c, 0, c->P, c->d1.nsplit));
+        TRY(launch_post(c, 0, c->P, 1));
     }
     TRY(launch_gram(c, 0, c->A32, nullptr, true));
     if (c->pipelined) {
@@ -399,8 +423,8 @@ static int prepare_trYBA(vbmf_ctx* c, int* flag) {
     double* dst = c->st + c->lay.scal() + S_TRDOT;
     HIPCHK(c, hipMemsetAsync(dst, 0, sizeof(double), c->stream));
     if (c->P_valid) {
-        const float* In = c->o.nranks > 1 ? c->Pred : c->P;
-        const int ns = c->o.nranks > 1 ? 1 : c->d1.nsplit;
+        const float* In = (c->o.nranks > 1 || c->d1.nsplit > 1) ? c->Pred : c->P;
+        const int ns = 1;
         const long long ld = (long long)c->d1.XT * 32;
         hipLaunchKernelGGL(dot_kernel, dim3(grid_for(c->M, 256, 1024)), dim3(256), 0, c->stream, In, ld, ns,
                            (long long)c->Hp * ld, c->A32, c->Hp, (long long)c->M, dst);
@@ -518,8 +542,9 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
     } else { c->err = "bad y_dtype"; return bail(VBMF_ERR_INVALID); }
     c->kstep = kstep_of(c->mode);
     c->npart = npart_of(c->mode);
-    plan_pass(c->d1, M, L, c->kstep, c->NH, c->o.pass1_splits);
-    plan_pass(c->d2, L, M, c->kstep, c->NH, 0);
+    const double ybytes = c->mode == MODE_F32 ? 4.0 : 2.0;
+    plan_pass(c->d1, M, L, c->kstep, c->NH, c->Hp, ybytes, c->o.pass1_splits);
+    plan_pass(c->d2, L, M, c->kstep, c->NH, c->Hp, ybytes, 0);
     c->Mp = (int64_t)c->d1.XT * 32;
     c->Lp = (int64_t)c->d2.XT * 32;
     // the post kernel writes operand tiles for every 32-row tile of the factor: the consumer's KS must cover them
@@ -545,7 +570,7 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
     ALLOC(c->FA, c->nFA * 16);
     ALLOC(c->P, (size_t)c->d1.nsplit * c->Hp * c->Mp * 4);
     ALLOC(c->Q, (size_t)c->d2.nsplit * c->Hp * c->Lp * 4);
-    if (c->o.nranks > 1) ALLOC(c->Pred, (size_t)c->Hp * c->Mp * 4);
+    if (c->o.nranks > 1 || c->d1.nsplit > 1) ALLOC(c->Pred, (size_t)c->Hp * c->Mp * 4);
     ALLOC(c->A32, (size_t)c->Mp * c->Hp * 4);
     ALLOC(c->B32[0], (size_t)c->Lp * c->Hp * 4);
     ALLOC(c->B32[1], (size_t)c->Lp * c->Hp * 4);
@@ -559,16 +584,26 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
     ALLOC(c->mask, (size_t)c->Mp);
 #undef ALLOC
     if (hipHostMalloc((void**)&c->ints_host, 16 * sizeof(int)) != hipSuccess ||
-        hipHostMalloc((void**)&c->scal_host, 32 * sizeof(double)) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
-        c->err = "pinned alloc / stream create failed"; return bail(VBMF_ERR_HIP);
+        hipHostMalloc((void**)&c->scal_host, 32 * sizeof(double)) != hipSuccess) {
+        c->err = "pinned alloc failed"; return bail(VBMF_ERR_HIP);
+    }
+    {
+        // CU-mask bit i addresses XCD i % 8, CU i / 8 of that XCD (probed with HW_REG_XCC_ID/HW_ID)
+        const int ncu = prop.multiProcessorCount;
+        std::vector<uint32_t> mmain((ncu + 31) / 32, 0u), mside((ncu + 31) / 32, 0u);
+        const int nmain = ncu - SIDE_CU;
+        for (int i = 0; i < ncu; ++i) ((i < nmain) ? mmain : mside)[i / 32] |= 1u << (i % 32);
+        if (ncu != NUM_CU + SIDE_CU ||
+            hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)mmain.size(), mmain.data()) != hipSuccess ||
+            hipExtStreamCreateWithCUMask(&c->side, (uint32_t)mside.size(), mside.data()) != hipSuccess) {
+            c->err = "CU-masked stream creation failed (expected a 256-CU MI355X)"; return bail(VBMF_ERR_HIP);
+        }
     }
     // large dynamic LDS (160 KiB per CU on gfx950) for the lambda_max kernel at 64 < H <= 128
     c->lds_limit = 160 * 1024 - 4096;
     if (hipFuncSetAttribute((const void*)eig_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit) != hipSuccess) {
         c->err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"; return bail(VBMF_ERR_HIP);
     }
-    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) { c->err = "side stream create failed"; return bail(VBMF_ERR_HIP); }
     for (auto& e : c->ev)
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { c->err = "event create failed"; return bail(VBMF_ERR_HIP); }
     // the zero-fills above ran on the null stream; all later work runs on a non-blocking stream
