@@ -134,15 +134,19 @@ __device__ __forceinline__ void gj_tiled(double (&w)[R][R], int n, double* strip
     }
 }
 
+// relaxed agent-scope read of the loop's stop flag (bypasses this CU's L1: the flag may have been
+// raised a moment ago by ctrl_end in this very workgroup or by another one)
+__device__ __forceinline__ int load_stop(const int* ints) {
+    return __hip_atomic_load(ints + I_STOP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // which = 0: SigmaA from (GB, SigmaB, ca), N = L_global.  which = 1: SigmaB from (GA, SigmaA, cb), N = M.
-// Launch with T*T threads and LDS for (4*T*R + T*R) doubles.
+// Needs T*T threads and (4*T*R + T*R) doubles of LDS at `lds`; every thread of the block must call it.
 template <int R, int T>
-__global__ __launch_bounds__(T * T) void ctrl_cov_kernel(double* __restrict__ st, StateLayout lay, int H, int which,
-                                                         double N, float* __restrict__ S32, int* __restrict__ ints) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+__device__ __forceinline__ void ctrl_cov_dev(double* __restrict__ st, StateLayout lay, int H, int which, double N,
+                                             float* __restrict__ S32, int* __restrict__ ints, double* lds) {
     __shared__ double red[16];
-    if (ints[I_STOP]) return;
-    // (no s_setprio: A/B)
+    if (load_stop(ints)) return;
     constexpr int NP = T * R;
     const int Hp = lay.Hp;
     const int tx = threadIdx.x % T, ty = threadIdx.x / T;
@@ -193,6 +197,13 @@ __global__ __launch_bounds__(T * T) void ctrl_cov_kernel(double* __restrict__ st
     if (threadIdx.x == 0) scal[which == 0 ? S_LOGDET_SA : S_LOGDET_SB] = (double)H * log(sigma2) - ld;
 }
 
+template <int R, int T>
+__global__ __launch_bounds__(T * T) void ctrl_cov_kernel(double* __restrict__ st, StateLayout lay, int H, int which,
+                                                         double N, float* __restrict__ S32, int* __restrict__ ints) {
+    extern __shared__ __attribute__((aligned(16))) double lds_cov[];
+    ctrl_cov_dev<R, T>(st, lay, H, which, N, S32, ints, lds_cov);
+}
+
 // lambda_max of a symmetric PSD H x H matrix: block 0 -> GD (S_LAMD), block 1 -> GB (S_LAMB_NEW).
 // spectral = 0: Frobenius surrogate (trace) instead.
 //
@@ -204,18 +215,13 @@ __global__ __launch_bounds__(T * T) void ctrl_cov_kernel(double* __restrict__ st
 // of the same matrix measured 2.9 ms on one CU; this is a few tens of microseconds.
 constexpr int EIG_NSQ = 14;
 
+// which = 0: GD -> S_LAMD, 1: GB -> S_LAMB_NEW.  256 threads, 2*NP*(NP+4) floats of LDS (NP = 16R).
 template <int R>
-__global__ __launch_bounds__(256) void eig_kernel(double* __restrict__ st, StateLayout lay, int H, int spectral,
-                                                  int do_d, int do_b, const int* __restrict__ ints) {
-    extern __shared__ __attribute__((aligned(16))) float ldsf[];
+__device__ __forceinline__ void eig_dev(double* __restrict__ st, StateLayout lay, int H, int spectral, int which,
+                                        const int* __restrict__ ints, float* ldsf) {
     __shared__ double red[16];
     __shared__ int s_arg;
-    if (ints[I_STOP]) return;
-    // this workgroup shares the chip (often a CU) with the streaming pass it overlaps: its few waves sit
-    // on the sweep's dependency chain, the streaming waves do not -- take issue priority over them
-    // (no s_setprio: A/B)
-    const int which = blockIdx.x;           // 0: GD, 1: GB
-    if ((which == 0 && !do_d) || (which == 1 && !do_b)) return;
+    if (load_stop(ints)) return;
     const int Hp = lay.Hp;
     const double* G = st + (which == 0 ? lay.GD() : lay.GB());
     double* scal = st + lay.scal();
@@ -309,6 +315,16 @@ __global__ __launch_bounds__(256) void eig_kernel(double* __restrict__ st, State
     num = block_sum(num, red);
     den = block_sum(den, red);
     if (threadIdx.x == 0) scal[slot] = den > 0.0 ? num / den : 0.0;
+    __syncthreads();                                         // LDS is reused by whatever the block runs next
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void eig_kernel(double* __restrict__ st, StateLayout lay, int H, int spectral,
+                                                  int do_d, int do_b, const int* __restrict__ ints) {
+    extern __shared__ __attribute__((aligned(16))) float lds_eig[];
+    const int which = blockIdx.x;           // 0: GD, 1: GB
+    if ((which == 0 && !do_d) || (which == 1 && !do_b)) return;
+    eig_dev<R>(st, lay, H, spectral, which, ints, lds_eig);
 }
 
 // Fallback for H > 128 (matrix does not fit the squaring kernel's LDS tiles): cyclic Jacobi with
@@ -405,12 +421,11 @@ __global__ void eig_jacobi_kernel(double* __restrict__ st, StateLayout lay, int 
 
 // flags: bit0 est_covs->CA, bit1 est_covs->CB, bit2 est_var, bit3 compute d + loop bookkeeping,
 //        bit4 tr(Y'BA') from the Gram identity tr(KB o GB) (else from scal[S_TRDOT])
-__global__ __launch_bounds__(256) void ctrl_end_kernel(double* __restrict__ st, StateLayout lay, int H, double Lg,
-                                                       double M, int flags, double eps,
-                                                       double* __restrict__ trace, int* __restrict__ ints) {
+__device__ __forceinline__ void ctrl_end_dev(double* __restrict__ st, StateLayout lay, int H, double Lg, double M,
+                                             int flags, double eps, double* __restrict__ trace,
+                                             int* __restrict__ ints) {
     __shared__ double red[16];
-    if (ints[I_STOP]) return;
-    // (no s_setprio: A/B)
+    if (load_stop(ints)) return;
     const int Hp = lay.Hp;
     const double* GA = st + lay.GA();
     const double* GB = st + lay.GB();
@@ -463,9 +478,43 @@ __global__ __launch_bounds__(256) void ctrl_end_kernel(double* __restrict__ st, 
             const int it = ints[I_ITERS];
             if (trace) { trace[4 * it + 0] = d; trace[4 * it + 1] = sigma2; trace[4 * it + 2] = F; trace[4 * it + 3] = resid; }
             ints[I_ITERS] = it + 1;
-            if (!(d > eps) || it + 1 >= ints[I_NITER]) ints[I_STOP] = 1;    // src/vbmf.jl:193 (NaN d exits too)
+            if (!(d > eps) || it + 1 >= ints[I_NITER])                     // src/vbmf.jl:193 (NaN d exits too)
+                __hip_atomic_store(ints + I_STOP, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    __threadfence();
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void ctrl_end_kernel(double* __restrict__ st, StateLayout lay, int H, double Lg,
+                                                       double M, int flags, double eps,
+                                                       double* __restrict__ trace, int* __restrict__ ints) {
+    ctrl_end_dev(st, lay, H, Lg, M, flags, eps, trace, ints);
+}
+
+// ---- the control chain as run by workgroup 0 of a streaming-pass launch ----------------------------
+// The H x H algebra of a sweep depends only on Grams that are complete before the pass is launched
+// and produces what the kernels AFTER the pass need, so one extra workgroup of the pass runs it while
+// the others stream: one stream, no events, kernel boundaries give all ordering and visibility.
+struct CtrlArgs {
+    double* st; StateLayout lay; int* ints; double* trace;
+    float* S32;            // SigmaA/sigma2 (pass 1) or SigmaB/sigma2 (pass 2) table for the post kernel
+    double Lg, M, eps;
+    int H, spectral, end_flags;
+    int mode;              // bit0: lambda_max(GD), lambda_max(GB) + ctrl_end of the PREVIOUS sweep;
+                           // bit1: SigmaA; bit2: SigmaB; 0: no control workgroup in this launch
+};
+enum : int { CTRL_PREV_END = 1, CTRL_COV_A = 2, CTRL_COV_B = 4 };
+
+template <int R>
+__device__ __forceinline__ void ctrl_chain(const CtrlArgs& a, void* lds) {
+    if (a.mode & CTRL_PREV_END) {
+        eig_dev<R>(a.st, a.lay, a.H, a.spectral, 0, a.ints, reinterpret_cast<float*>(lds));
+        eig_dev<R>(a.st, a.lay, a.H, a.spectral, 1, a.ints, reinterpret_cast<float*>(lds));
+        ctrl_end_dev(a.st, a.lay, a.H, a.Lg, a.M, a.end_flags, a.eps, a.trace, a.ints);
+    }
+    if (a.mode & CTRL_COV_A) ctrl_cov_dev<R, 16>(a.st, a.lay, a.H, 0, a.Lg, a.S32, a.ints, reinterpret_cast<double*>(lds));
+    if (a.mode & CTRL_COV_B) ctrl_cov_dev<R, 16>(a.st, a.lay, a.H, 1, a.M, a.S32, a.ints, reinterpret_cast<double*>(lds));
 }
 
 __global__ void copy_scalar_kernel(double* st, StateLayout lay, int dst, int src) {

@@ -115,6 +115,178 @@ __global__ __launch_bounds__(256) void post_kernel(const float* __restrict__ In,
     }
 }
 
+// ---- fused post + Gram (NH <= 2) ---------------------------------------------------------------------
+// Same update as post_kernel, and while the new 32-row tile still sits in accumulator registers its
+// Gram contribution (and, against the previous factor, the delta-Gram) is added with the tile fed back
+// as BOTH MFMA operands (the contraction runs over the row index that lives in registers: no
+// transpose, no LDS).  Waves walk tiles with stride gridDim*4; the four waves of a workgroup fold their
+// register partials through LDS into one slab per workgroup (upper-triangular tile pairs only).
+//   slabs: [gridDim.x][2 (Gram, delta)][NPAIR][16 regs][64 lanes] fp32
+template <int MODE, int NH>
+__global__ __launch_bounds__(256) void post_gram_kernel(const float* __restrict__ In, long long ldIn, int nslab,
+                                                        long long slabStride, const float* __restrict__ S,
+                                                        float* __restrict__ Fac, const float* __restrict__ Prev,
+                                                        uint4* __restrict__ Ft, const unsigned char* __restrict__ mask,
+                                                        int hmask_start, int XT, float* __restrict__ slabs,
+                                                        const int* __restrict__ stop) {
+    static_assert(NH <= 2, "fused Gram keeps NH(NH+1)/2 pair tiles per matrix in registers");
+    constexpr int Hp = NH * 32;
+    constexpr int NPAIR = NH * (NH + 1) / 2;
+    __shared__ float fold[2 * NPAIR * 16 * 64];
+    if (stop && *stop) return;
+    const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6;
+    const int c = lane & 31, half = lane >> 5;
+    f32x16 G[NPAIR], D[NPAIR];
+#pragma unroll
+    for (int p = 0; p < NPAIR; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { G[p][r] = 0.f; D[p][r] = 0.f; }
+
+    // this lane's slice of the Sigma/sigma2 table, loaded once (the same for every tile):
+    // sreg[hin][t][h] = S[hin*32 + 2t + half][h*32 + c]
+    float sreg[NH][16][NH];
+#pragma unroll
+    for (int hin = 0; hin < NH; ++hin)
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+#pragma unroll
+            for (int h = 0; h < NH; ++h) sreg[hin][t][h] = S[(long long)(hin * 32 + 2 * t + half) * Hp + h * 32 + c];
+
+    for (int xt = blockIdx.x * 4 + wib; xt < XT; xt += gridDim.x * 4) {
+        const long long x0 = (long long)xt * 32;
+        // issue every load of the tile before the first MFMA (one wave per SIMD: latency is hidden by
+        // loads in flight, not by other waves)
+        float areg[NH][16];
+#pragma unroll
+        for (int hin = 0; hin < NH; ++hin)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const float* ip = In + (long long)(hin * 32 + 2 * t + half) * ldIn + x0 + c;
+                float a = ip[0];
+                for (int s = 1; s < nslab; ++s) a += ip[(long long)s * slabStride];
+                areg[hin][t] = a;
+            }
+        f32x16 pv[NH];
+        if (Prev != nullptr) {
+#pragma unroll
+            for (int h = 0; h < NH; ++h)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pv[h][r] = Prev[(x0 + rho(r, half)) * Hp + h * 32 + c];
+        }
+        f32x16 acc[NH];
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[h][r] = 0.f;
+#pragma unroll
+        for (int hin = 0; hin < NH; ++hin)
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+#pragma unroll
+                for (int h = 0; h < NH; ++h)
+                    acc[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[hin][t], sreg[hin][t][h], acc[h], 0, 0, 0);
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const int hcol = h * 32 + c;
+            if (mask != nullptr && hcol >= hmask_start) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (mask[x0 + rho(r, half)]) acc[h][r] = 0.f;
+            }
+            write_factor_tiles<MODE, NH>(Ft, acc[h], xt, h, lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Fac[(x0 + rho(r, half)) * Hp + hcol] = acc[h][r];
+        }
+        // Gram of the new tile: pair index p runs over h1 <= h2
+        {
+            int p = 0;
+#pragma unroll
+            for (int h1 = 0; h1 < NH; ++h1)
+#pragma unroll
+                for (int h2 = h1; h2 < NH; ++h2, ++p)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float u = acc[h1][r], v = acc[h2][r];
+                        G[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(u, v, G[p], 0, 0, 0);
+                    }
+        }
+        if (Prev != nullptr) {
+            f32x16 dv[NH];
+#pragma unroll
+            for (int h = 0; h < NH; ++h)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float cur = acc[h][r], old = pv[h][r];
+                    dv[h][r] = old - cur;
+                }
+            int p = 0;
+#pragma unroll
+            for (int h1 = 0; h1 < NH; ++h1)
+#pragma unroll
+                for (int h2 = h1; h2 < NH; ++h2, ++p)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float u = dv[h1][r], v = dv[h2][r];
+                        D[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(u, v, D[p], 0, 0, 0);
+                    }
+        }
+    }
+    // fold the four waves' partials (fixed order => deterministic), then one coalesced slab store
+    for (int wv = 0; wv < 4; ++wv) {
+        if (wib == wv) {
+#pragma unroll
+            for (int p = 0; p < NPAIR; ++p)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ig = (p * 16 + r) * 64 + lane, id = ((NPAIR + p) * 16 + r) * 64 + lane;
+                    const float g = G[p][r], d = D[p][r];
+                    if (wv == 0) { fold[ig] = g; fold[id] = d; }
+                    else { fold[ig] += g; fold[id] += d; }
+                }
+        }
+        __syncthreads();
+    }
+    float* o = slabs + (long long)blockIdx.x * (2 * NPAIR * 1024);
+    for (int i = threadIdx.x; i < 2 * NPAIR * 1024; i += 256) o[i] = fold[i];
+}
+
+// fp64 reduction of the post_gram slabs into dense Hp x Hp matrices (both triangles).
+//   one thread per (matrix, pair, reg, lane) x 4 slab groups; LDS fold of the groups.
+template <int NH>
+__global__ __launch_bounds__(1024) void pair_slab_reduce_kernel(const float* __restrict__ slabs, int nslab,
+                                                                double* __restrict__ outG, double* __restrict__ outD,
+                                                                const int* __restrict__ stop) {
+    constexpr int Hp = NH * 32;
+    constexpr int NPAIR = NH * (NH + 1) / 2;
+    constexpr int NOUT = 2 * NPAIR * 1024;
+    constexpr int NG = 16;
+    __shared__ double part[NG][64];
+    if (stop && *stop) return;
+    const int j = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + j;                       // (mat, pair, r, lane) flat, grid = NOUT/64
+    double s = 0.0;
+#pragma unroll 4
+    for (int k = g; k < nslab; k += NG) s += (double)slabs[(long long)k * NOUT + idx];
+    part[g][j] = s;
+    __syncthreads();
+    if (g == 0) {
+        s = 0.0;
+#pragma unroll
+        for (int q = 0; q < NG; ++q) s += part[q][j];
+        const int mat = idx / (NPAIR * 1024), rem = idx % (NPAIR * 1024);
+        const int p = rem / 1024, r = (rem % 1024) / 64, lane = rem % 64;
+        int h1 = 0, h2 = 0, q = 0;
+        for (int a = 0; a < NH; ++a) for (int b = a; b < NH; ++b, ++q) if (q == p) { h1 = a; h2 = b; }
+        const int row = h1 * 32 + rho(r, lane >> 5), col = h2 * 32 + (lane & 31);
+        double* out = mat ? outD : outG;
+        if (out != nullptr) {
+            out[(long long)row * Hp + col] = s;
+            if (h1 != h2) out[(long long)col * Hp + row] = s;
+        }
+    }
+}
+
 template <int MODE, int NH>
 __global__ __launch_bounds__(256) void retile_kernel(float* __restrict__ Fac, uint4* __restrict__ Ft, int XT) {
     constexpr int Hp = NH * 32;

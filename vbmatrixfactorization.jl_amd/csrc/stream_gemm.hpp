@@ -27,34 +27,50 @@
 //     register is 32 consecutive x of one h row -> two 128-byte segments per store instruction.
 //   * Split-K partials go to per-split slabs with plain stores (deterministic; the consumer sums them
 //     while it loads), not atomics.
+//   * Workgroup 0 of a launch may run the sweep's H x H control chain (ctrl_kernels.hpp, CtrlArgs)
+//     instead of streaming: its inputs are complete before the launch and its outputs are needed only
+//     after it, so the chain overlaps the pass for free.
 //   * Grid: per-CU throughput is latency-bound, so time = the most loaded CU: the planner (host) picks
 //     the split factor that makes the block count one balanced wave over the 256 CUs
 //     (measured at 100k x 10k: 240 blocks 5.7 TB/s, 260 blocks 3.3 TB/s).
 #pragma once
 #include "common.hpp"
+#include "ctrl_kernels.hpp"
 
 namespace vbmf {
 
 // cache policy of the Y stream: 2 = nt (streamed once); 0 = default
 constexpr int Y_AUX = 2;
 
-template <int MODE, int NH, int NXW_, int DY, int DF>
+template <int MODE, int NH, int NXW_, int DY, int DF, int RCTRL>
 __global__ __launch_bounds__(256) void stream_gemm_kernel(const uint4* __restrict__ Yt,   // [XT][KS][64]
                                                           const uint4* __restrict__ Ft,   // [KS][NPART][NH][64]
                                                           float* __restrict__ Out,        // [nsplit][NH*32][ldOut]
                                                           int XG, int KS, int steps_per_split, int nsplit,
-                                                          long long ldOut, const int* __restrict__ stop) {
+                                                          long long ldOut, const int* __restrict__ stop,
+                                                          CtrlArgs ctrl) {
     constexpr int NPART = ModeTraits<MODE>::NPART;
     constexpr int NF = NPART * NH;
     static_assert(PIPE_D % DY == 0 && DY % DF == 0, "ring depths must divide the padding quantum");
     static_assert(XT_PAD % NXW_ == 0, "tiles per wave must divide the x padding quantum");
+    int bid = blockIdx.x;
+    if (ctrl.mode != 0) {                                 // launch carries a control workgroup (dispatched first)
+        if (bid == 0) {
+            if constexpr (RCTRL > 0) {
+                extern __shared__ __attribute__((aligned(16))) unsigned char ctrl_lds[];
+                ctrl_chain<RCTRL>(ctrl, ctrl_lds);
+            }
+            return;
+        }
+        bid -= 1;
+    }
     if (stop && *stop) return;
 
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform => SGPR addressing
     const int bps = (XG + 3) >> 2;                       // blocks per split
-    const int split = blockIdx.x / bps;
-    const int xg = (blockIdx.x % bps) * 4 + wib;
+    const int split = bid / bps;
+    const int xg = (bid % bps) * 4 + wib;
     if (xg >= XG || split >= nsplit) return;              // wave-uniform
 
     const long long ks0 = (long long)split * steps_per_split;

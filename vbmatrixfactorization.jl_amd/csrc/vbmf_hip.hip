@@ -66,9 +66,11 @@ struct vbmf_ctx {
     int64_t H1 = 0;
     bool has_mask = false;
     hipStream_t stream = nullptr;
-    hipStream_t side = nullptr;       // H x H control kernels run here, overlapped with the streaming passes
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    bool pipelined = false;           // inside vbmf_run: control kernels go to `side`
+    bool in_run = false;              // inside vbmf_run: the control chain rides in workgroup 0 of the pass launches
+    bool tail_pending = false;        // eig + ctrl_end of the last enqueued sweep not issued yet
+    int run_flags = 0;
+    double run_eps = 0.0;
+    double* run_trace = nullptr;
     bool haveY = false, haveState = false;
     bool gA_valid = false, gB_valid = false, P_valid = false, kb_identity = false;
     double trYY_local = 0.0;
@@ -136,17 +138,14 @@ static inline int grid_for(int64_t n, int block = 256, int cap = 8192) {
 // per-NH geometry of the streaming kernel: NXW * NH = 8 accumulator tiles (128 registers) per wave,
 // Y ring DY and factor ring DF k-steps deep (register budget: 128 + 4*(DY*NXW + DF*NF) + addressing)
 template <int NH> struct StreamCfg;
-template <> struct StreamCfg<1> { static constexpr int NXWc = 8; static constexpr int DYc = 3; static constexpr int DFc = 3; };
-template <> struct StreamCfg<2> { static constexpr int NXWc = 4; static constexpr int DYc = 6; static constexpr int DFc = 2; };
-template <> struct StreamCfg<4> { static constexpr int NXWc = 2; static constexpr int DYc = 6; static constexpr int DFc = 2; };
-template <> struct StreamCfg<8> { static constexpr int NXWc = 1; static constexpr int DYc = 4; static constexpr int DFc = 1; };
+template <> struct StreamCfg<1> { static constexpr int NXWc = 8; static constexpr int DYc = 3; static constexpr int DFc = 3; static constexpr int Rc = 2; };
+template <> struct StreamCfg<2> { static constexpr int NXWc = 4; static constexpr int DYc = 6; static constexpr int DFc = 2; static constexpr int Rc = 4; };
+template <> struct StreamCfg<4> { static constexpr int NXWc = 2; static constexpr int DYc = 6; static constexpr int DFc = 2; static constexpr int Rc = 8; };
+template <> struct StreamCfg<8> { static constexpr int NXWc = 1; static constexpr int DYc = 4; static constexpr int DFc = 1; static constexpr int Rc = 0; };
 
 static int nxw_of(int NH) { return 8 / NH; }
-// The main stream is CU-masked to 240 of the 256 CUs (30 per XCD); the remaining 2 per XCD belong to the
-// side stream so the H x H control kernels never share a CU with a streaming block (measured: sharing
-// stretches the streaming pass by the control chain's length because the pass ends with its slowest CU).
-constexpr int NUM_CU = 240;
-constexpr int SIDE_CU = 16;
+// one CU is left to the control workgroup that rides in each pass launch
+constexpr int NUM_CU = 255;
 
 // Split-K plan.  A CU's streaming rate is latency-bound (bytes in flight / latency; measured ~30 GB/s
 // per CU for this kernel, i.e. ~190 busy CUs already saturate HBM), so a pass takes
@@ -206,7 +205,16 @@ static void prof_harvest(vbmf_ctx* c) {
     c->pev.clear();
 }
 
-static int launch_stream(vbmf_ctx* c, int pass) {
+static size_t ctrl_lds_bytes(int NH) {
+    const int R = NH <= 4 ? 2 * NH : 0;
+    if (R == 0) return 0;
+    const size_t NP = 16 * (size_t)R;
+    return std::max((size_t)2 * NP * (NP + 4) * sizeof(float), (size_t)5 * 16 * R * sizeof(double));
+}
+static bool fused_ctrl(const vbmf_ctx* c) { return c->in_run && c->NH <= 4; }
+
+// ctrl_mode != 0: workgroup 0 of the launch runs that part of the control chain (CtrlArgs)
+static int launch_stream(vbmf_ctx* c, int pass, int ctrl_mode = 0) {
     const Dims& d = pass == 0 ? c->d1 : c->d2;
     const uint4* Y = pass == 0 ? c->Y1 : c->Y2;
     const uint4* F = pass == 0 ? c->FB : c->FA;
@@ -214,12 +222,19 @@ static int launch_stream(vbmf_ctx* c, int pass) {
     const long long ld = (long long)d.XT * 32;
     const int XG = d.XT / nxw_of(c->NH);
     const int bps = (XG + 3) / 4;
-    const int grid = bps * d.nsplit;
+    const int grid = bps * d.nsplit + (ctrl_mode ? 1 : 0);
+    CtrlArgs ca{};
+    ca.st = c->st; ca.lay = c->lay; ca.ints = c->ints; ca.trace = c->run_trace;
+    ca.S32 = pass == 0 ? c->SA32 : c->SB32;
+    ca.Lg = (double)c->Lg; ca.M = (double)c->M; ca.eps = c->run_eps;
+    ca.H = (int)c->H; ca.spectral = (c->o.reference_compat & VBMF_COMPAT_SPECTRAL_DELTA) ? 1 : 0;
+    ca.end_flags = c->run_flags; ca.mode = ctrl_mode;
+    const size_t lds = ctrl_mode ? ctrl_lds_bytes(c->NH) : 0;
     prof_begin(c, pass);
     DISPATCH_MODE(c->mode, DISPATCH_NH(c->NH, {
         using Cfg = StreamCfg<NHc>;
-        hipLaunchKernelGGL((stream_gemm_kernel<MODEc, NHc, Cfg::NXWc, Cfg::DYc, Cfg::DFc>), dim3(grid), dim3(256), 0, c->stream,
-                           Y, F, out, XG, d.KS, d.steps_per_split, d.nsplit, ld, c->ints + I_STOP);
+        hipLaunchKernelGGL((stream_gemm_kernel<MODEc, NHc, Cfg::NXWc, Cfg::DYc, Cfg::DFc, Cfg::Rc>), dim3(grid), dim3(256), lds,
+                           c->stream, Y, F, out, XG, d.KS, d.steps_per_split, d.nsplit, ld, c->ints + I_STOP, ca);
     }));
     prof_end(c);
     HIPCHK(c, hipGetLastError());
@@ -241,6 +256,42 @@ static int launch_post(vbmf_ctx* c, int which, const float* In, int nslab) {
                            Fac, Ft, mk, hstart, d.XT, c->ints + I_STOP);
     }));
     HIPCHK(c, hipGetLastError());
+    return VBMF_OK;
+}
+
+// fused post + Gram (+ delta-Gram) for NH <= 2; reduction into the state block (or the all-reduce staging)
+static bool fused_gram(const vbmf_ctx* c) { return c->NH <= 2; }
+
+static int launch_post_gram(vbmf_ctx* c, int which, const float* In, int nslab) {
+    const Dims& d = which == 0 ? c->d1 : c->d2;
+    const long long ld = (long long)d.XT * 32;
+    const long long slabStride = (long long)c->Hp * ld;
+    const float* S = which == 0 ? c->SA32 : c->SB32;
+    float* Fac = which == 0 ? c->A32 : c->B32[c->bcur ^ 1];
+    const float* Prev = which == 0 ? nullptr : c->B32[c->bcur];
+    uint4* Ft = which == 0 ? c->FA : c->FB;
+    const unsigned char* mk = (which == 0 && c->has_mask) ? c->mask : nullptr;
+    const int hstart = (int)(c->H - c->H1);
+    const int grid = std::min(256, (d.XT + 3) / 4);
+    const int* stop = c->ints + I_STOP;
+    DISPATCH_MODE(c->mode, {
+        if (c->NH == 1) hipLaunchKernelGGL((post_gram_kernel<MODEc, 1>), dim3(grid), dim3(256), 0, c->stream, In, ld, nslab, slabStride, S, Fac, Prev, Ft, mk, hstart, d.XT, c->gslab, stop);
+        else hipLaunchKernelGGL((post_gram_kernel<MODEc, 2>), dim3(grid), dim3(256), 0, c->stream, In, ld, nslab, slabStride, S, Fac, Prev, Ft, mk, hstart, d.XT, c->gslab, stop);
+    });
+    const int n = c->Hp * c->Hp;
+    const bool shard = (which == 1 && c->o.nranks > 1);
+    double* outG = shard ? c->gtmp : c->st + (which == 0 ? c->lay.GA() : c->lay.GB());
+    double* outD = which == 0 ? nullptr : (shard ? c->gtmp + n : c->st + c->lay.GD());
+    if (c->NH == 1) hipLaunchKernelGGL((pair_slab_reduce_kernel<1>), dim3(2 * 1 * 1024 / 64), dim3(1024), 0, c->stream, c->gslab, grid, outG, outD, stop);
+    else hipLaunchKernelGGL((pair_slab_reduce_kernel<2>), dim3(2 * 3 * 1024 / 64), dim3(1024), 0, c->stream, c->gslab, grid, outG, outD, stop);
+    HIPCHK(c, hipGetLastError());
+    if (shard) {
+        if (!c->comm_ready) FAIL(c, VBMF_ERR_COMM, "nranks > 1 but vbmf_comm_init was not called");
+        NCCLCHK(c, ncclAllReduce(c->gtmp, c->gtmp, 2 * (size_t)n, ncclDouble, ncclSum, c->comm, c->stream));
+        hipLaunchKernelGGL(gated_copy_kernel, dim3((2 * n + 255) / 256), dim3(256), 0, c->stream, c->gtmp,
+                           c->st + c->lay.GB(), 2 * n, stop);
+        HIPCHK(c, hipGetLastError());
+    }
     return VBMF_OK;
 }
 
@@ -286,7 +337,7 @@ static int launch_gram(vbmf_ctx* c, int which, const float* cur, const float* pr
 
 static int ctrl_threads(int H) { return H <= 16 ? 64 : (H <= 32 ? 256 : 1024); }
 
-static hipStream_t ctrl_stream(vbmf_ctx* c) { return c->pipelined ? c->side : c->stream; }
+static hipStream_t ctrl_stream(vbmf_ctx* c) { return c->stream; }
 
 template <int R, int T>
 static void launch_cov_t(vbmf_ctx* c, int which, hipStream_t s) {
@@ -366,16 +417,19 @@ static int ensure_gram_B(vbmf_ctx* c) {
     return VBMF_OK;
 }
 
-// Ordering when pipelined (vbmf_run): control kernels are issued on `side`, everything that touches
-// L x H / M x H data on `stream`; ev[0] = SigmaA ready, ev[1] = A'A ready, ev[2] = SigmaB ready,
-// ev[3] = B Grams ready.  The streaming pass itself needs none of the control results, so it
-// overlaps the control kernels of the same half-sweep.
+// Inside vbmf_run (NH <= 4) the control chain rides in workgroup 0 of the pass launches:
+//   pass 1 of sweep i : [lambda_max + ctrl_end of sweep i-1] + SigmaA of sweep i
+//   pass 2 of sweep i : SigmaB of sweep i
+// Outside (vbmf_step, H > 128) the same device code runs as stand-alone kernels before the pass.
 static int do_update_A(vbmf_ctx* c) {
     TRY(ensure_gram_B(c));
-    TRY(launch_ctrl_cov(c, 0));
-    if (c->pipelined) HIPCHK(c, hipEventRecord(c->ev[0], c->side));
-    TRY(launch_stream(c, 0));
-    if (c->pipelined) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev[0], 0));
+    if (fused_ctrl(c)) {
+        TRY(launch_stream(c, 0, CTRL_COV_A | (c->tail_pending ? CTRL_PREV_END : 0)));
+        c->tail_pending = false;
+    } else {
+        TRY(launch_ctrl_cov(c, 0));
+        TRY(launch_stream(c, 0));
+    }
     if (c->o.nranks > 1 || c->d1.nsplit > 1) {
         const long long n = (long long)c->Hp * c->d1.XT * 32;
         hipLaunchKernelGGL(slab_sum_kernel, dim3(grid_for(n / 4, 256, 2048)), dim3(256), 0, c->stream, c->P, c->d1.nsplit, n,
@@ -383,15 +437,13 @@ static int do_update_A(vbmf_ctx* c) {
         HIPCHK(c, hipGetLastError());
         if (c->o.nranks > 1)
             NCCLCHK(c, ncclAllReduce(c->Pred, c->Pred, (size_t)n, ncclFloat, ncclSum, c->comm, c->stream));
-        TRY(launch_post(c, 0, c->Pred, 1));
+        if (fused_gram(c)) TRY(launch_post_gram(c, 0, c->Pred, 1));
+        else TRY(launch_post(c, 0, c->Pred, 1));
     } else {
-        TRY(launch_post(c, 0, c->P, 1));
+        if (fused_gram(c)) TRY(launch_post_gram(c, 0, c->P, 1));
+        else TRY(launch_post(c, 0, c->P, 1));
     }
-    TRY(launch_gram(c, 0, c->A32, nullptr, true));
-    if (c->pipelined) {
-        HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-        HIPCHK(c, hipStreamWaitEvent(c->side, c->ev[1], 0));
-    }
+    if (!fused_gram(c)) TRY(launch_gram(c, 0, c->A32, nullptr, true));
     c->gA_valid = true;
     c->P_valid = true;
     c->kb_identity = false;
@@ -400,15 +452,17 @@ static int do_update_A(vbmf_ctx* c) {
 
 static int do_update_B(vbmf_ctx* c) {
     TRY(ensure_gram_A(c));
-    TRY(launch_ctrl_cov(c, 1));
-    if (c->pipelined) HIPCHK(c, hipEventRecord(c->ev[2], c->side));
-    TRY(launch_stream(c, 1));
-    if (c->pipelined) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev[2], 0));
-    TRY(launch_post(c, 1, c->Q, c->d2.nsplit));
-    TRY(launch_gram(c, 1, c->B32[c->bcur ^ 1], c->B32[c->bcur], true));
-    if (c->pipelined) {
-        HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-        HIPCHK(c, hipStreamWaitEvent(c->side, c->ev[3], 0));
+    if (fused_ctrl(c)) {
+        TRY(launch_stream(c, 1, CTRL_COV_B));
+    } else {
+        TRY(launch_ctrl_cov(c, 1));
+        TRY(launch_stream(c, 1));
+    }
+    if (fused_gram(c)) {
+        TRY(launch_post_gram(c, 1, c->Q, c->d2.nsplit));
+    } else {
+        TRY(launch_post(c, 1, c->Q, c->d2.nsplit));
+        TRY(launch_gram(c, 1, c->B32[c->bcur ^ 1], c->B32[c->bcur], true));
     }
     c->bcur ^= 1;
     c->gB_valid = true;
@@ -491,8 +545,6 @@ int vbmf_destroy(vbmf_ctx* c) {
     for (void* b : bufs) if (b) hipFree(b);
     if (c->ints_host) hipHostFree(c->ints_host);
     if (c->scal_host) hipHostFree(c->scal_host);
-    for (auto& e : c->ev) if (e) hipEventDestroy(e);
-    if (c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
     return VBMF_OK;
@@ -577,7 +629,7 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
     ALLOC(c->SA32, (size_t)c->Hp * c->Hp * 4);
     ALLOC(c->SB32, (size_t)c->Hp * c->Hp * 4);
     const int nchunk = std::max(cdiv(c->d1.XT, c->tiles_per_chunk), cdiv(c->d2.XT, c->tiles_per_chunk));
-    ALLOC(c->gslab, (size_t)nchunk * 2 * c->Hp * c->Hp * 4);
+    ALLOC(c->gslab, std::max((size_t)nchunk * 2 * c->Hp * c->Hp * 4, (size_t)256 * 2 * 3 * 1024 * 4));
     ALLOC(c->st, (size_t)c->lay.total() * 8);
     ALLOC(c->gtmp, (size_t)2 * c->Hp * c->Hp * 8);
     ALLOC(c->ints, 16 * sizeof(int));
@@ -587,25 +639,20 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
         hipHostMalloc((void**)&c->scal_host, 32 * sizeof(double)) != hipSuccess) {
         c->err = "pinned alloc failed"; return bail(VBMF_ERR_HIP);
     }
-    {
-        // CU-mask bit i addresses XCD i % 8, CU i / 8 of that XCD (probed with HW_REG_XCC_ID/HW_ID)
-        const int ncu = prop.multiProcessorCount;
-        std::vector<uint32_t> mmain((ncu + 31) / 32, 0u), mside((ncu + 31) / 32, 0u);
-        const int nmain = ncu - SIDE_CU;
-        for (int i = 0; i < ncu; ++i) ((i < nmain) ? mmain : mside)[i / 32] |= 1u << (i % 32);
-        if (ncu != NUM_CU + SIDE_CU ||
-            hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)mmain.size(), mmain.data()) != hipSuccess ||
-            hipExtStreamCreateWithCUMask(&c->side, (uint32_t)mside.size(), mside.data()) != hipSuccess) {
-            c->err = "CU-masked stream creation failed (expected a 256-CU MI355X)"; return bail(VBMF_ERR_HIP);
-        }
-    }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { c->err = "stream create failed"; return bail(VBMF_ERR_HIP); }
     // large dynamic LDS (160 KiB per CU on gfx950) for the lambda_max kernel at 64 < H <= 128
     c->lds_limit = 160 * 1024 - 4096;
-    if (hipFuncSetAttribute((const void*)eig_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit) != hipSuccess) {
-        c->err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"; return bail(VBMF_ERR_HIP);
+    {
+        hipError_t e = hipFuncSetAttribute((const void*)eig_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
+        if (e == hipSuccess && c->NH == 4) {
+            using Cfg = StreamCfg<4>;
+            DISPATCH_MODE(c->mode, {
+                e = hipFuncSetAttribute((const void*)stream_gemm_kernel<MODEc, 4, Cfg::NXWc, Cfg::DYc, Cfg::DFc, Cfg::Rc>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
+            });
+        }
+        if (e != hipSuccess) { c->err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"; return bail(VBMF_ERR_HIP); }
     }
-    for (auto& e : c->ev)
-        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { c->err = "event create failed"; return bail(VBMF_ERR_HIP); }
     // the zero-fills above ran on the null stream; all later work runs on a non-blocking stream
     // that does not order against it, so drain the device once here
     if (hipDeviceSynchronize() != hipSuccess) { c->err = "hipDeviceSynchronize failed"; return bail(VBMF_ERR_HIP); }
@@ -878,33 +925,37 @@ int vbmf_run(vbmf_ctx* c, int64_t niter, double eps, int est_covs, int est_var, 
     }
     const int flags = (est_covs ? 3 : 0) | (est_var ? 4 : 0) | 8 | 16;
     const int bstart = c->bcur;
-    // from here on: control kernels on `side` (ordered after everything issued so far)
-    if (rc == VBMF_OK) {
-        hipError_t e = hipEventRecord(c->ev[3], c->stream);
-        if (e == hipSuccess) e = hipStreamWaitEvent(c->side, c->ev[3], 0);
-        if (e != hipSuccess) { c->err = std::string("pipeline setup: ") + hipGetErrorString(e); rc = VBMF_ERR_HIP; }
-        c->pipelined = true;
-    }
+    c->in_run = true;
+    c->tail_pending = false;
+    c->run_flags = flags;
+    c->run_eps = eps;
+    c->run_trace = trace_dev;
     const int64_t check = 8;
     int64_t it = 0;
     bool stopped = false;
     while (rc == VBMF_OK && it < niter && !stopped) {
-        rc = do_update_A(c);
+        rc = do_update_A(c);                 // carries lambda_max + ctrl_end of the previous sweep when fused
         if (rc == VBMF_OK) rc = do_update_B(c);
-        if (rc == VBMF_OK) rc = launch_eig(c, 1, 1);
-        if (rc == VBMF_OK) rc = launch_ctrl_end(c, flags, eps, trace_dev);
         ++it;
-        if (rc == VBMF_OK && (it % check == 0 || it == niter)) {
-            // the loop test lives at the end of the side stream's ctrl_end
-            hipError_t e = hipMemcpyAsync(c->ints_host, c->ints, 4 * sizeof(int), hipMemcpyDeviceToHost, c->side);
-            if (e == hipSuccess) e = hipStreamSynchronize(c->side);
+        const bool checkpoint = (it % check == 0 || it == niter);
+        if (rc == VBMF_OK) {
+            if (fused_ctrl(c) && !checkpoint) {
+                c->tail_pending = true;      // rides in the next sweep's pass-1 launch
+            } else {
+                rc = launch_eig(c, 1, 1);
+                if (rc == VBMF_OK) rc = launch_ctrl_end(c, flags, eps, trace_dev);
+            }
+        }
+        if (rc == VBMF_OK && checkpoint) {
+            hipError_t e = hipMemcpyAsync(c->ints_host, c->ints, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
             if (e != hipSuccess) { c->err = std::string("run loop sync: ") + hipGetErrorString(e); rc = VBMF_ERR_HIP; break; }
             if (c->ints_host[I_STOP] || c->ints_host[I_ERR]) stopped = true;
         }
     }
-    c->pipelined = false;
-    hipStreamSynchronize(c->side);
+    c->in_run = false;
+    c->tail_pending = false;
+    c->run_trace = nullptr;
     hipStreamSynchronize(c->stream);
     if (rc == VBMF_OK) {
         hipError_t e = hipMemcpyAsync(c->ints_host, c->ints, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
