@@ -169,6 +169,16 @@ def main():
     avg_ms = (prof["pass1_ms"] + prof["pass2_ms"]) / max(n, 1)
     avg_bytes = (bytes1 * prof["pass1_n"] + bytes2 * prof["pass2_n"]) / max(n, 1)
     achieved = avg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    # HBM traffic per launch from PMC counters is collected in separate rocprofv3 passes
+    # (scripts/pmc_traffic.sh); report the committed measurement when it is for exactly this workload
+    traffic = None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_c_pmc_stream_kernel_cfg3.json")))
+        k = pm["config"]
+        if (k["L"], k["M"], k["H"], k["y_dtype"], k["n_gpus"]) == (L, M, H, ydt, world) and a.factor in ("auto", "bf16x2"):
+            traffic = pm["traffic_bytes_per_launch"]
+    except Exception:
+        traffic = None
     out = {
         "metric": "VB iterations/sec",
         "value": a.steps / elapsed,
@@ -188,7 +198,7 @@ def main():
                    "accumulate": "fp32", "hxh_algebra": "fp64", "row_shards": world},
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "kernel": "stream_gemm_kernel (pass 1: Y'B, pass 2: Y*A; this rank's shard)",
             "bytes_per_launch": avg_bytes, "avg_launch_ms": avg_ms, "launches": n,
             "pass1": {"ms": prof["pass1_ms"] / max(prof["pass1_n"], 1), "bytes": bytes1,

@@ -147,8 +147,8 @@ static int nxw_of(int NH) { return 8 / NH; }
 // one CU is left to the control workgroup that rides in each pass launch
 constexpr int NUM_CU = 255;
 
-// Split-K plan.  A CU's streaming rate is latency-bound (bytes in flight / latency; measured ~30 GB/s
-// per CU for this kernel, i.e. ~190 busy CUs already saturate HBM), so a pass takes
+// Split-K plan.  A CU streams at most ~24-30 GB/s with this kernel (so ~220+ busy CUs are needed to
+// saturate HBM), and a pass ends with its most loaded CU, so it takes
 //     max( rounds * bytes_per_block / R_CU ,  total_bytes / R_HBM )  +  slab write+read
 // with rounds = ceil(blocks / 256).  Pick the split factor minimising that (measured at 100k x 10k:
 // 240 blocks 0.35 ms, 260 blocks 0.61 ms, 160 blocks 0.44 ms -- the model's ordering).
@@ -159,7 +159,7 @@ static void plan_pass(Dims& d, int64_t X, int64_t K, int kstep, int NH, int Hp, 
     const int bps = (XG + 3) / 4;
     int ns = want_splits;
     if (ns <= 0) {
-        const double R_CU = 30e9, R_HBM = 5.9e12;
+        const double R_CU = 24e9, R_HBM = 5.4e12;   // measured in the sweep pipeline (200 vs 240 blocks: 0.434 vs 0.390 ms)
         const double total = (double)d.XT * 32.0 * (double)ks_min * kstep * ybytes;
         const double out_bytes = (double)Hp * d.XT * 32.0 * 4.0;
         const int ns_max = (int)std::max<int64_t>(1, std::min<int64_t>(64, ks_min / (2 * PIPE_D)));
