@@ -301,3 +301,28 @@ def test_config2_shape_three_sweeps(pkg, mode):
     report(f"cfg2 {mode}: " + " ".join(f"{k}={v:.2e}" for k, v in errs.items()))
     assert max(errs[k] for k in ("A", "B", "SA", "SB", "ca", "cb")) < 4 * tol["default"], errs
     assert errs["s2"] < 4 * tol["sigma2"] and errs["d"] < 5e-3 and errs["elbo"] < 1e-4, errs
+
+
+def test_single_rank_communicator_runs_the_collective_path(pkg):
+    """Only one GPU is available to the tests: attach a 1-rank RCCL communicator, which switches the
+    library onto the row-sharded code path (all-reduce of the Y'B partial, of the packed Grams and of
+    ||Y||^2, staging + gated copy) and compare with the plain path -- a sum over one rank must be
+    bit-identical.  Also checks that the state stays frozen after the loop has stopped."""
+    L, M, H = 700, 520, 24
+    Y, po = _problem(L, M, H, 901, separated=True)
+    res = []
+    for with_comm in (False, True):
+        with pkg.capi.Context(L, M, H, y_dtype=pkg.VBMF_Y_BF16) as c:
+            if with_comm:
+                c.comm_init(pkg.capi.Context.unique_id())
+            c.set_Y(Y)
+            c.set_state(po.AHat, po.BHat, po.SigmaA, po.SigmaB, np.diag(po.CA), np.diag(po.CB), po.sigma2)
+            it, d, tr = c.run(30, eps=2e-3, est_covs=True, est_var=True, want_trace=True)
+            s = c.get_state()
+            res.append((it, d, tr.copy(), s, c.trYY(), c.elbo()))
+    (it0, d0, tr0, s0, t0, e0), (it1, d1, tr1, s1, t1, e1) = res
+    assert 3 < it0 < 30 and it0 == it1 and d0 == d1 and t0 == t1
+    assert np.array_equal(tr0, tr1)
+    for k in ("AHat", "BHat", "SigmaA", "SigmaB", "CA_diag", "CB_diag"):
+        assert np.array_equal(s0[k], s1[k]), k
+    assert s0["sigma2"] == s1["sigma2"] and abs(e0 - e1) <= 1e-9 * abs(e0)

@@ -50,6 +50,15 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # Load order matters in a process that also uses PyTorch-ROCm: torch bundles its own copies of
+    # libamdhip64/librccl (same SONAMEs as /opt/rocm's).  If torch is imported AFTER this library the
+    # process aborts at interpreter exit (double free in the duplicated runtime); torch first is fine --
+    # this library then binds to the runtime torch loaded.  So load torch (when present) first.  It is
+    # not used for anything here.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python vbmatrixfactorization.jl_amd/build.py` "

@@ -84,6 +84,9 @@ struct vbmf_ctx {
     int lds_limit = 65536;
 };
 
+// the collective code path runs whenever a communicator is attached (also a 1-rank one: used to test it)
+static bool sharded(const vbmf_ctx* c) { return c->comm_ready; }
+
 // ------------------------------------------------------------------------------------------------
 #define FAIL(ctx, code, ...)                                   \
     do {                                                       \
@@ -279,7 +282,7 @@ static int launch_post_gram(vbmf_ctx* c, int which, const float* In, int nslab) 
         else hipLaunchKernelGGL((post_gram_kernel<MODEc, 2>), dim3(grid), dim3(256), 0, c->stream, In, ld, nslab, slabStride, S, Fac, Prev, Ft, mk, hstart, d.XT, c->gslab, stop);
     });
     const int n = c->Hp * c->Hp;
-    const bool shard = (which == 1 && c->o.nranks > 1);
+    const bool shard = (which == 1 && sharded(c));
     double* outG = shard ? c->gtmp : c->st + (which == 0 ? c->lay.GA() : c->lay.GB());
     double* outD = which == 0 ? nullptr : (shard ? c->gtmp + n : c->st + c->lay.GD());
     if (c->NH == 1) hipLaunchKernelGGL((pair_slab_reduce_kernel<1>), dim3(2 * 1 * 1024 / 64), dim3(1024), 0, c->stream, c->gslab, grid, outG, outD, stop);
@@ -318,7 +321,7 @@ static int launch_gram(vbmf_ctx* c, int which, const float* cur, const float* pr
                            c->tiles_per_chunk, nchunk, stop);
     });
     const int n = c->Hp * c->Hp;
-    const bool shard = (which == 1 && c->o.nranks > 1);
+    const bool shard = (which == 1 && sharded(c));
     double* outG = shard ? c->gtmp : c->st + (which == 0 ? c->lay.GA() : c->lay.GB());
     double* outD = which == 0 ? nullptr : (shard ? c->gtmp + n : c->st + c->lay.GD());
     hipLaunchKernelGGL(gram_reduce_kernel, dim3((2 * n + 255) / 256), dim3(256), 0, c->stream, c->gslab, nchunk, n,
@@ -430,12 +433,12 @@ static int do_update_A(vbmf_ctx* c) {
         TRY(launch_ctrl_cov(c, 0));
         TRY(launch_stream(c, 0));
     }
-    if (c->o.nranks > 1 || c->d1.nsplit > 1) {
+    if (sharded(c) || c->d1.nsplit > 1) {
         const long long n = (long long)c->Hp * c->d1.XT * 32;
         hipLaunchKernelGGL(slab_sum_kernel, dim3(grid_for(n / 4, 256, 2048)), dim3(256), 0, c->stream, c->P, c->d1.nsplit, n,
                            c->Pred, n, c->ints + I_STOP);
         HIPCHK(c, hipGetLastError());
-        if (c->o.nranks > 1)
+        if (sharded(c))
             NCCLCHK(c, ncclAllReduce(c->Pred, c->Pred, (size_t)n, ncclFloat, ncclSum, c->comm, c->stream));
         if (fused_gram(c)) TRY(launch_post_gram(c, 0, c->Pred, 1));
         else TRY(launch_post(c, 0, c->Pred, 1));
@@ -477,7 +480,7 @@ static int prepare_trYBA(vbmf_ctx* c, int* flag) {
     double* dst = c->st + c->lay.scal() + S_TRDOT;
     HIPCHK(c, hipMemsetAsync(dst, 0, sizeof(double), c->stream));
     if (c->P_valid) {
-        const float* In = (c->o.nranks > 1 || c->d1.nsplit > 1) ? c->Pred : c->P;
+        const float* In = (sharded(c) || c->d1.nsplit > 1) ? c->Pred : c->P;
         const int ns = 1;
         const long long ld = (long long)c->d1.XT * 32;
         hipLaunchKernelGGL(dot_kernel, dim3(grid_for(c->M, 256, 1024)), dim3(256), 0, c->stream, In, ld, ns,
@@ -487,7 +490,7 @@ static int prepare_trYBA(vbmf_ctx* c, int* flag) {
         const long long ld = (long long)c->d2.XT * 32;
         hipLaunchKernelGGL(dot_kernel, dim3(grid_for(c->L, 256, 1024)), dim3(256), 0, c->stream, c->Q, ld, c->d2.nsplit,
                            (long long)c->Hp * ld, c->B32[c->bcur], c->Hp, (long long)c->L, dst);
-        if (c->o.nranks > 1) NCCLCHK(c, ncclAllReduce(dst, dst, 1, ncclDouble, ncclSum, c->comm, c->stream));
+        if (sharded(c)) NCCLCHK(c, ncclAllReduce(dst, dst, 1, ncclDouble, ncclSum, c->comm, c->stream));
     }
     HIPCHK(c, hipGetLastError());
     *flag = 0;
@@ -622,7 +625,7 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
     ALLOC(c->FA, c->nFA * 16);
     ALLOC(c->P, (size_t)c->d1.nsplit * c->Hp * c->Mp * 4);
     ALLOC(c->Q, (size_t)c->d2.nsplit * c->Hp * c->Lp * 4);
-    if (c->o.nranks > 1 || c->d1.nsplit > 1) ALLOC(c->Pred, (size_t)c->Hp * c->Mp * 4);
+    ALLOC(c->Pred, (size_t)c->Hp * c->Mp * 4);
     ALLOC(c->A32, (size_t)c->Mp * c->Hp * 4);
     ALLOC(c->B32[0], (size_t)c->Lp * c->Hp * 4);
     ALLOC(c->B32[1], (size_t)c->Lp * c->Hp * 4);
@@ -685,7 +688,7 @@ static int finish_Y(vbmf_ctx* c) {
     HIPCHK(c, hipMemcpyAsync(c->scal_host, tr, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->trYY_local = c->scal_host[0];
-    c->trYY_reduced = (c->o.nranks == 1);
+    c->trYY_reduced = !sharded(c) && c->o.nranks == 1;
     c->haveY = true;
     c->P_valid = false;
     c->kb_identity = false;
@@ -762,7 +765,7 @@ int vbmf_get_trYY(vbmf_ctx* c, double* trYY) {
     if (!c || !trYY) return VBMF_ERR_INVALID;
     if (!c->haveY) FAIL(c, VBMF_ERR_INVALID, "no Y");
     HIPCHK(c, hipSetDevice(c->o.device));
-    if (c->o.nranks > 1 && !c->trYY_reduced) { *trYY = c->trYY_local; return VBMF_OK; }
+    if (!c->trYY_reduced) { *trYY = c->trYY_local; return VBMF_OK; }     // this rank's part until the first step/run
     HIPCHK(c, hipMemcpyAsync(c->scal_host, c->st + c->lay.scal() + S_TRYY, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     *trYY = c->scal_host[0];
@@ -1039,6 +1042,8 @@ int vbmf_comm_init(vbmf_ctx* c, const void* id128) {
     memcpy(&id, id128, sizeof id);
     NCCLCHK(c, ncclCommInitRank(&c->comm, c->o.nranks, id, c->o.rank));
     c->comm_ready = true;
+    c->trYY_reduced = false;          // ||Y||^2 (if already set) must be summed over the ranks
+    c->gA_valid = c->gB_valid = false;
     return VBMF_OK;
 }
 
