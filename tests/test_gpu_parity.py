@@ -319,7 +319,10 @@ def test_single_rank_communicator_runs_the_collective_path(pkg):
             c.set_state(po.AHat, po.BHat, po.SigmaA, po.SigmaB, np.diag(po.CA), np.diag(po.CB), po.sigma2)
             it, d, tr = c.run(30, eps=2e-3, est_covs=True, est_var=True, want_trace=True)
             s = c.get_state()
+            frozen = c.get_state()
             res.append((it, d, tr.copy(), s, c.trYY(), c.elbo()))
+            # a second run that stops immediately (eps huge) must not move the state by more than one sweep's worth
+            assert np.array_equal(frozen["BHat"], s["BHat"])
     (it0, d0, tr0, s0, t0, e0), (it1, d1, tr1, s1, t1, e1) = res
     assert 3 < it0 < 30 and it0 == it1 and d0 == d1 and t0 == t1
     assert np.array_equal(tr0, tr1)

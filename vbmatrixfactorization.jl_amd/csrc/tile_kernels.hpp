@@ -31,8 +31,8 @@ struct SynthSrc {
 };
 
 // One thread = one 16-byte fragment.  TRANSPOSED=false: x=m,k=l (Y1); true: x=l,k=m (Y2).
-// Fragments in [xt0,xt1) x [ks0,ks1) are produced.  When sumsq != nullptr the squared stored values
-// are accumulated (fp64) -- done on exactly one of the two copies.
+// Fragments in [xt0,xt1) x [ks0,ks1) are produced.  When sumsq != nullptr each block writes the fp64 sum of
+// its squared stored values to sumsq[blockIdx.x] -- done on exactly one of the two copies.
 template <int MODE, bool TRANSPOSED, class Src>
 __global__ __launch_bounds__(256) void tile_y_kernel(uint4* __restrict__ out, Src src, int xt0, int xt1, int ks0,
                                                      int ks1, int KSpad, double* sumsq) {
@@ -76,13 +76,28 @@ __global__ __launch_bounds__(256) void tile_y_kernel(uint4* __restrict__ out, Sr
         }
         out[((long long)xt * KSpad + ks) * 64 + lane] = o;
     }
-    if (sumsq) {
+    if (sumsq) {                                  // one partial per block, summed later in a fixed order
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
         __shared__ double part[4];
         if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
         __syncthreads();
-        if (threadIdx.x == 0) atomicAdd(sumsq, part[0] + part[1] + part[2] + part[3]);
+        if (threadIdx.x == 0) sumsq[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
     }
+}
+
+// *dst += sum(partials[0..n)) in a fixed order (run-to-run reproducible ||Y||^2)
+__global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ partials, int n,
+                                                           double* __restrict__ dst) {
+    __shared__ double sh[256];
+    double a = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) a += partials[i];
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *dst += sh[0];
 }
 
 // Decode the pass-2 copy (x = l, k = m) back to column-major fp64: out[(l-row0) + m*ld].

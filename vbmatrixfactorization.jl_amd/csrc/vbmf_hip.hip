@@ -58,6 +58,7 @@ struct vbmf_ctx {
     int tiles_per_chunk = 32;
     double* st = nullptr;
     double* gtmp = nullptr;          // 2*Hp^2 local Gram sums (all-reduce staging)
+    double* ypart = nullptr;         // per-block partials of ||Y||^2 (fixed-order sum)
     StateLayout lay{};
     int* ints = nullptr;
     int* ints_host = nullptr;        // pinned
@@ -544,7 +545,7 @@ int vbmf_destroy(vbmf_ctx* c) {
     prof_harvest(c);
     if (c->comm) ncclCommDestroy(c->comm);
     void* bufs[] = {c->Y1, c->Y2, c->FA, c->FB, c->P, c->Q, c->Pred, c->A32, c->B32[0], c->B32[1], c->SA32,
-                    c->SB32, c->gslab, c->st, c->gtmp, c->ints, c->mask};
+                    c->SB32, c->gslab, c->st, c->gtmp, c->ypart, c->ints, c->mask};
     for (void* b : bufs) if (b) hipFree(b);
     if (c->ints_host) hipHostFree(c->ints_host);
     if (c->scal_host) hipHostFree(c->scal_host);
@@ -635,6 +636,7 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
     ALLOC(c->gslab, std::max((size_t)nchunk * 2 * c->Hp * c->Hp * 4, (size_t)256 * 2 * 3 * 1024 * 4));
     ALLOC(c->st, (size_t)c->lay.total() * 8);
     ALLOC(c->gtmp, (size_t)2 * c->Hp * c->Hp * 8);
+    ALLOC(c->ypart, (size_t)16384 * 8);
     ALLOC(c->ints, 16 * sizeof(int));
     ALLOC(c->mask, (size_t)c->Mp);
 #undef ALLOC
@@ -676,8 +678,10 @@ static int build_tiles(vbmf_ctx* c, const Src& src, int64_t m0, int64_t m1, doub
         constexpr int TM = (MODEc == MODE_F32) ? MODE_F32 : MODE_BF16;
         hipLaunchKernelGGL((tile_y_kernel<TM, false, Src>), dim3(grid_for(n1, 256, 16384)), dim3(256), 0, c->stream, c->Y1,
                            src, xt0, xt1, 0, c->d1.KS, c->d1.KS, (double*)nullptr);
-        hipLaunchKernelGGL((tile_y_kernel<TM, true, Src>), dim3(grid_for(n2, 256, 16384)), dim3(256), 0, c->stream, c->Y2,
-                           src, 0, c->d2.XT, ks0, ks1, c->d2.KS, sumsq);
+        const int g2 = grid_for(n2, 256, 16384);
+        hipLaunchKernelGGL((tile_y_kernel<TM, true, Src>), dim3(g2), dim3(256), 0, c->stream, c->Y2,
+                           src, 0, c->d2.XT, ks0, ks1, c->d2.KS, sumsq ? c->ypart : nullptr);
+        if (sumsq) hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, c->stream, c->ypart, g2, sumsq);
     });
     HIPCHK(c, hipGetLastError());
     return VBMF_OK;
