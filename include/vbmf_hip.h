@@ -122,6 +122,37 @@ int vbmf_get_YHat(vbmf_ctx* ctx, double* YHat, int64_t ld);
 /* Build-defined ELBO of the basic model (the reference has none). */
 int vbmf_elbo(vbmf_ctx* ctx, double* elbo);
 
+/* ---- ARD-sparse variant: src/vbmf_sparse.jl with full_cov=false, diag_var=false (opts.variant =
+ * VBMF_VARIANT_SPARSE_DIAG).  vec(A') is element-wise: index m*H + h (src/vbmf_sparse.jl:119,244-246).
+ * Shapes: ATVecHat, diagSigmaATVec, CA, beta: M*H; BHat: L x H column-major; SigmaB: H x H; CB, delta: H.
+ * sigmaHat is the noise PRECISION with Gamma posterior (eta, zeta) (src/vbmf_sparse.jl:35-39,321).
+ * Derived constants (src/vbmf_sparse.jl:131,137,143): alpha = alpha0 + 1/2, gamma = gamma0 + L/2,
+ * eta = eta0 + L*M/2 (L = L_global).  The full-covariance branch (dense MH x MH) and diag_var=true are
+ * out of scope. */
+typedef struct { double alpha0, beta0, gamma0, delta0, eta0, zeta0; } vbmf_sparse_hyper;
+
+#define VBMF_SSTEP_A 1      /* updateA! diagonal branch  src/vbmf_sparse.jl:204-247 */
+#define VBMF_SSTEP_B 2      /* updateB!                  src/vbmf_sparse.jl:263-266 */
+#define VBMF_SSTEP_CA 4     /* updateCA!                 src/vbmf_sparse.jl:284-288 */
+#define VBMF_SSTEP_CB 8     /* updateCB!                 src/vbmf_sparse.jl:295-300 */
+#define VBMF_SSTEP_SIGMA 16 /* updateSigma! homoscedastic src/vbmf_sparse.jl:317-321 */
+
+int vbmf_sparse_set_state(vbmf_ctx* ctx, const double* ATVecHat, const double* diagSigmaATVec, const double* CA,
+                          const double* beta, const double* BHat, int64_t ldB, const double* SigmaB,
+                          const double* CB, const double* delta, double sigmaHat, double zeta,
+                          const vbmf_sparse_hyper* hyper, const int64_t* labels0, int64_t nlabels, int64_t H1);
+/* any output pointer may be NULL; SigmaA_diag: the diagonal of SigmaA (H), src/vbmf_sparse.jl:236-239 */
+int vbmf_sparse_get_state(vbmf_ctx* ctx, double* ATVecHat, double* diagSigmaATVec, double* CA, double* beta,
+                          double* SigmaA_diag, double* BHat, int64_t ldB, double* SigmaB, double* CB,
+                          double* delta, double* sigmaHat, double* zeta);
+int vbmf_sparse_step(vbmf_ctx* ctx, int which);            /* reference order A, B, CA, CB, SIGMA (:369-376) */
+/* vbmf_sparse! loop (src/vbmf_sparse.jl:344-410): returns d like the reference; trace: niter x 4 (d, sigmaHat, 0, 0) */
+int vbmf_sparse_run(vbmf_ctx* ctx, int64_t niter, double eps, int est_cb, int64_t* iters_done, double* d_last,
+                    double* trace);
+/* lowerBound (src/vbmf_sparse.jl:435-471), verbatim quirks QS4; H(B) as L*logdet(SigmaB), clamped like
+ * normalEntropy's det (src/util.jl:118-122) when clamp != 0 */
+int vbmf_sparse_lower_bound(vbmf_ctx* ctx, int clamp, double* lb);
+
 /* ---- multi-GPU: one process per GPU, Y row-sharded, RCCL all-reduce of Y'B and of the Grams ---- */
 #define VBMF_UNIQUE_ID_BYTES 128
 int vbmf_comm_unique_id(void* id128);                       /* rank 0 creates, host broadcasts */

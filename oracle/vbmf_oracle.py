@@ -47,7 +47,8 @@ def spectral_norm(X):
 
 def delta(new, old):
     """src/util.jl:27-29 -- norm(old-new)/norm(old) with operator 2-norms."""
-    return spectral_norm(old - new) / spectral_norm(old)
+    with np.errstate(divide="ignore", invalid="ignore"):          # Julia: 0/0 = NaN, x/0 = Inf (no exception)
+        return float(np.float64(spectral_norm(old - new)) / np.float64(spectral_norm(old)))
 
 
 def traceXTY(X, Y):

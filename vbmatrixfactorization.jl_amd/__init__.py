@@ -32,10 +32,13 @@ import numpy as np
 
 from . import capi
 from .capi import (Context, VbmfError, VBMF_Y_F32, VBMF_Y_BF16, VBMF_FACTOR_AUTO, VBMF_FACTOR_BF16,
-                   VBMF_FACTOR_BF16X2, STEP_A, STEP_B, STEP_CA, STEP_CB, STEP_SIGMA2)
+                   VBMF_FACTOR_BF16X2, VBMF_VARIANT_SPARSE_DIAG, STEP_A, STEP_B, STEP_CA, STEP_CB, STEP_SIGMA2,
+                   SSTEP_A, SSTEP_B, SSTEP_CA, SSTEP_CB, SSTEP_SIGMA)
 
 __all__ = ["vbmf_parameters", "vbmf_init", "vbmf", "vbmf_", "copy", "updateA_", "updateB_", "updateCA_",
-           "updateCB_", "updateSigma2_", "updateYHat_", "elbo", "Session", "set_defaults", "capi"]
+           "updateCB_", "updateSigma2_", "updateYHat_", "elbo", "Session", "set_defaults", "capi",
+           "vbmf_sparse_parameters", "vbmf_sparse_init", "vbmf_sparse", "vbmf_sparse_", "lowerBound",
+           "sparse_updateA_", "sparse_updateB_", "sparse_updateCA_", "sparse_updateCB_", "sparse_updateSigma_"]
 
 # YHat (L x M float64) is materialised eagerly by the reference (src/vbmf.jl:70,217); above this many
 # elements the field is left None and computed on demand with updateYHat_ (8 GB at 100k x 10k).
@@ -275,3 +278,176 @@ def vbmf(Y, params_in, niter, **kw):
     # (SURVEY App. A Q2); keep params_in reusable as the docstring at :235 promises
     p.CA, p.CB = p.CA.copy(), p.CB.copy()
     return vbmf_(Y, p, niter, **kw)
+
+
+# =================================================================================================
+# ARD-sparse variant -- src/vbmf_sparse.jl with full_cov=false, diag_var=false
+# =================================================================================================
+@dataclass
+class vbmf_sparse_parameters:
+    """src/vbmf_sparse.jl:47-90 -- same field names and order.  SigmaATVec/invSigmaATVec (dense MH x MH,
+    eagerly eye()'d by the reference at :120,122) are left None: they belong to the full_cov branch only
+    and cannot exist at scale.  sigmaVecHat/etaVec/zetaVec belong to diag_var=true."""
+    L: int = 0
+    M: int = 0
+    H: int = 0
+    MH: int = 0
+    H1: int = 0
+    labels: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=np.int64))   # 1-based
+    AHat: Optional[np.ndarray] = None
+    ATVecHat: Optional[np.ndarray] = None
+    SigmaATVec: Optional[np.ndarray] = None
+    diagSigmaATVec: Optional[np.ndarray] = None
+    invSigmaATVec: Optional[np.ndarray] = None
+    SigmaA: Optional[np.ndarray] = None
+    BHat: Optional[np.ndarray] = None
+    SigmaB: Optional[np.ndarray] = None
+    CA: Optional[np.ndarray] = None
+    alpha0: float = 1e-10
+    beta0: float = 1e-10
+    alpha: float = 0.0
+    beta: Optional[np.ndarray] = None
+    CB: Optional[np.ndarray] = None
+    gamma0: float = 1e-10
+    delta0: float = 1e-10
+    gamma: float = 0.0
+    delta: Optional[np.ndarray] = None
+    sigmaHat: float = 1.0
+    eta0: float = 1e-10
+    zeta0: float = 1e-10
+    eta: float = 0.0
+    zeta: float = 0.0
+    sigmaVecHat: Optional[np.ndarray] = None
+    etaVec: Optional[np.ndarray] = None
+    zetaVec: Optional[np.ndarray] = None
+    YHat: Optional[np.ndarray] = None
+    trYTY: float = 0.0
+
+
+def vbmf_sparse_init(Y, H, ca=1.0, alpha0=1e-10, beta0=1e-10, cb=1.0, gamma0=1e-10, delta0=1e-10, sigma=1.0,
+                     eta0=1e-10, zeta0=1e-10, H1=0, labels=(), rng=None):
+    """src/vbmf_sparse.jl:101-153 (host side)."""
+    Y = np.asarray(Y)
+    rng = np.random.default_rng() if rng is None else rng
+    p = vbmf_sparse_parameters()
+    L, M = Y.shape
+    p.L, p.M, p.H, p.MH, p.H1 = L, M, int(H), M * int(H), int(H1)
+    p.labels = np.asarray(labels, dtype=np.int64)
+    p.AHat = rng.standard_normal((M, H))
+    if p.H1 > 0 and p.labels.size:
+        p.AHat[_labels0(p), H - p.H1:] = 0.0
+    p.ATVecHat = p.AHat.reshape(M * H).copy()
+    p.diagSigmaATVec = np.ones(M * H)
+    p.SigmaA = np.zeros((H, H))
+    p.BHat = rng.standard_normal((L, H))
+    p.SigmaB = np.zeros((H, H))
+    p.CA = ca * np.ones(M * H)
+    p.alpha0, p.beta0, p.alpha, p.beta = alpha0, beta0, alpha0 + 0.5, beta0 * np.ones(M * H)
+    p.CB = cb * np.ones(H)
+    p.gamma0, p.delta0, p.gamma, p.delta = gamma0, delta0, gamma0 + L / 2, delta0 * np.ones(H)
+    p.sigmaHat, p.eta0, p.zeta0, p.eta, p.zeta = float(sigma), eta0, zeta0, eta0 + L * M / 2, zeta0
+    p.YHat = p.BHat @ p.AHat.T if L * M <= YHAT_AUTO_LIMIT else None
+    p.trYTY = float(np.sum(Y * Y))
+    return p
+
+
+_sparse_sessions = {}
+
+
+def _sparse_ctx(Y, p):
+    Y = np.asarray(Y, dtype=np.float64)
+    key = (id(Y), Y.shape, Y.__array_interface__["data"][0], int(p.H), tuple(sorted(_defaults.items())))
+    ent = _sparse_sessions.get(key)
+    if ent is not None and ent[1]() is Y:
+        return ent[0]
+    for k in list(_sparse_sessions):
+        _sparse_sessions.pop(k)[0].close()
+    c = Context(Y.shape[0], Y.shape[1], p.H, variant=VBMF_VARIANT_SPARSE_DIAG, **_defaults)
+    c.set_Y(Y)
+    _sparse_sessions[key] = (c, weakref.ref(Y))
+    return c
+
+
+def _spush(c, p):
+    hyper = dict(alpha0=p.alpha0, beta0=p.beta0, gamma0=p.gamma0, delta0=p.delta0, eta0=p.eta0, zeta0=p.zeta0)
+    c.sparse_set_state(p.ATVecHat, p.diagSigmaATVec, p.CA, p.beta, p.BHat, p.SigmaB, p.CB, p.delta, p.sigmaHat,
+                       p.zeta, hyper, labels0=_labels0(p), H1=p.H1)
+
+
+def _spull(c, p):
+    s = c.sparse_get_state()
+    p.ATVecHat, p.diagSigmaATVec, p.CA, p.beta = s["ATVecHat"], s["diagSigmaATVec"], s["CA"], s["beta"]
+    p.AHat = p.ATVecHat.reshape(p.M, p.H).copy()
+    p.SigmaA = np.diag(s["SigmaA_diag"])
+    p.BHat, p.SigmaB, p.CB, p.delta = s["BHat"], s["SigmaB"], s["CB"], s["delta"]
+    p.sigmaHat, p.zeta = s["sigmaHat"], s["zeta"]
+
+
+def _sone(Y, p, which):
+    c = _sparse_ctx(Y, p)
+    _spush(c, p)
+    c.sparse_step(which)
+    _spull(c, p)
+
+
+def sparse_updateA_(Y, params, full_cov=False, diag_var=False):
+    """updateA! -- src/vbmf_sparse.jl:176-247 (diagonal branch only)."""
+    if full_cov or diag_var:
+        raise NotImplementedError("only full_cov=false, diag_var=false is built (SURVEY.md section 2)")
+    _sone(Y, params, SSTEP_A)
+
+
+def sparse_updateB_(Y, params, diag_var=False):
+    """updateB! -- src/vbmf_sparse.jl:254-268."""
+    if diag_var:
+        raise NotImplementedError("diag_var=true is out of scope")
+    _sone(Y, params, SSTEP_B)
+
+
+def sparse_updateCA_(params, Y=None):
+    """updateCA! -- src/vbmf_sparse.jl:284-288."""
+    _sone(Y, params, SSTEP_CA)
+
+
+def sparse_updateCB_(params, Y=None):
+    """updateCB! -- src/vbmf_sparse.jl:295-300."""
+    _sone(Y, params, SSTEP_CB)
+
+
+def sparse_updateSigma_(Y, params, diag_var=False):
+    """updateSigma! -- src/vbmf_sparse.jl:307-322 (homoscedastic)."""
+    if diag_var:
+        raise NotImplementedError("diag_var=true is out of scope")
+    _sone(Y, params, SSTEP_SIGMA)
+
+
+def vbmf_sparse_(Y, params, niter, eps=1e-6, diag_var=False, full_cov=False, logdir="", desc="", verb=False, est_cb=True):
+    """vbmf_sparse! -- src/vbmf_sparse.jl:344-410.  Returns d (like the reference)."""
+    if full_cov or diag_var:
+        raise NotImplementedError("only full_cov=false, diag_var=false is built (SURVEY.md section 2)")
+    if logdir != "":
+        raise NotImplementedError("per-iteration JLD logging is outside the accelerated path")
+    c = _sparse_ctx(Y, params)
+    _spush(c, params)
+    iters, d, _ = c.sparse_run(int(niter), eps=eps, est_cb=est_cb)
+    _spull(c, params)
+    params.YHat = params.BHat @ params.AHat.T if params.L * params.M <= YHAT_AUTO_LIMIT else None   # :396 (host, small only)
+    if verb:
+        print(f"Factorization finished after {iters} iterations, eps = {d}")
+    params._last_run = (iters, d)
+    return d
+
+
+def vbmf_sparse(Y, params_in, niter, **kw):
+    """vbmf_sparse -- src/vbmf_sparse.jl:418-428: deep-copies params_in (:160-168), returns (params, d)."""
+    import copy as _copy
+    p = _copy.deepcopy(params_in)
+    d = vbmf_sparse_(Y, p, niter, **kw)
+    return p, d
+
+
+def lowerBound(Y, params, clamp=True):
+    """lowerBound -- src/vbmf_sparse.jl:435-471."""
+    c = _sparse_ctx(Y, params)
+    _spush(c, params)
+    return c.sparse_lower_bound(clamp=clamp)

@@ -24,7 +24,9 @@ SYMBOLS = [
     "vbmf_get_Y", "vbmf_get_trYY", "vbmf_set_state", "vbmf_get_state", "vbmf_step", "vbmf_run", "vbmf_get_YHat",
     "vbmf_elbo", "vbmf_comm_unique_id", "vbmf_comm_init", "vbmf_profile_enable", "vbmf_profile_read",
     "vbmf_pass_bytes", "vbmf_device_sync", "vbmf_debug_peek",
+    "vbmf_sparse_set_state", "vbmf_sparse_get_state", "vbmf_sparse_step", "vbmf_sparse_run", "vbmf_sparse_lower_bound",
 ]
+SSTEP_A, SSTEP_B, SSTEP_CA, SSTEP_CB, SSTEP_SIGMA = 1, 2, 4, 8, 16
 PEEK_P, PEEK_Q, PEEK_A32, PEEK_B32, PEEK_FA, PEEK_FB, PEEK_Y1, PEEK_Y2, PEEK_DIMS = range(9)
 
 
@@ -34,6 +36,11 @@ class VbmfOpts(C.Structure):
         ("variant", C.c_int32), ("reference_compat", C.c_uint32), ("nranks", C.c_int32), ("rank", C.c_int32),
         ("L_global", C.c_int64), ("row_offset", C.c_int64), ("pass1_splits", C.c_int32), ("reserved", C.c_int32),
     ]
+
+
+class VbmfSparseHyper(C.Structure):
+    _fields_ = [("alpha0", C.c_double), ("beta0", C.c_double), ("gamma0", C.c_double), ("delta0", C.c_double),
+                ("eta0", C.c_double), ("zeta0", C.c_double)]
 
 
 class VbmfError(RuntimeError):
@@ -88,6 +95,12 @@ def lib():
     L.vbmf_pass_bytes.argtypes = [vp, i32, dp]
     L.vbmf_device_sync.argtypes = [vp]
     L.vbmf_debug_peek.argtypes = [vp, i32, C.POINTER(C.c_uint32), i64, i64]
+    L.vbmf_sparse_set_state.argtypes = [vp, dp, dp, dp, dp, dp, i64, dp, dp, dp, C.c_double, C.c_double,
+                                        C.POINTER(VbmfSparseHyper), C.POINTER(i64), i64, i64]
+    L.vbmf_sparse_get_state.argtypes = [vp, dp, dp, dp, dp, dp, dp, i64, dp, dp, dp, dp, dp]
+    L.vbmf_sparse_step.argtypes = [vp, i32]
+    L.vbmf_sparse_run.argtypes = [vp, i64, C.c_double, i32, C.POINTER(i64), dp, dp]
+    L.vbmf_sparse_lower_bound.argtypes = [vp, i32, dp]
     for name in SYMBOLS:
         if name not in ("vbmf_default_opts", "vbmf_last_error"):
             getattr(L, name).restype = C.c_int
@@ -111,11 +124,13 @@ class Context:
     """One problem on one GPU: thin, explicit wrapper over the C ABI (no numerics on the host)."""
 
     def __init__(self, L, M, H, y_dtype=VBMF_Y_BF16, factor_dtype=VBMF_FACTOR_AUTO, device=0, nranks=1, rank=0,
-                 L_global=0, row_offset=0, reference_compat=VBMF_COMPAT_DEFAULT, pass1_splits=0):
+                 L_global=0, row_offset=0, reference_compat=VBMF_COMPAT_DEFAULT, pass1_splits=0,
+                 variant=VBMF_VARIANT_BASIC):
         self._lib = lib()
         o = VbmfOpts()
         self._lib.vbmf_default_opts(C.byref(o))
         o.device, o.y_dtype, o.factor_dtype = device, y_dtype, factor_dtype
+        o.variant = variant
         o.nranks, o.rank, o.L_global, o.row_offset = nranks, rank, L_global, row_offset
         o.reference_compat, o.pass1_splits = reference_compat, pass1_splits
         self._h = C.c_void_p()
@@ -205,6 +220,48 @@ class Context:
     def elbo(self):
         v = C.c_double()
         self._chk(self._lib.vbmf_elbo(self._h, C.byref(v)))
+        return v.value
+
+    # ---- ARD-sparse variant (variant=VBMF_VARIANT_SPARSE_DIAG) ----
+    def sparse_set_state(self, ATVecHat, diagSigmaATVec, CA, beta, BHat, SigmaB, CB, delta, sigmaHat, zeta, hyper,
+                         labels0=(), H1=0):
+        n = self.M * self.H
+        vecs = [np.ascontiguousarray(v, dtype=np.float64) for v in (ATVecHat, diagSigmaATVec, CA, beta)]
+        for v in vecs:
+            if v.shape != (n,):
+                raise ValueError("vec(A')-shaped arguments must have length M*H")
+        B = _fcol(BHat, (self.L, self.H)); SB = _fcol(SigmaB, (self.H, self.H))
+        cb = np.ascontiguousarray(CB, dtype=np.float64); dl = np.ascontiguousarray(delta, dtype=np.float64)
+        hp = VbmfSparseHyper(*[float(hyper[k]) for k in ("alpha0", "beta0", "gamma0", "delta0", "eta0", "zeta0")])
+        lab = np.ascontiguousarray(labels0, dtype=np.int64)
+        self._chk(self._lib.vbmf_sparse_set_state(self._h, _dptr(vecs[0]), _dptr(vecs[1]), _dptr(vecs[2]), _dptr(vecs[3]),
+                                                  _dptr(B), self.L, _dptr(SB), _dptr(cb), _dptr(dl), float(sigmaHat),
+                                                  float(zeta), C.byref(hp), lab.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                  lab.size, int(H1)))
+
+    def sparse_get_state(self, want_B=True):
+        n = self.M * self.H
+        a, ds, ca, be = (np.empty(n) for _ in range(4))
+        sa = np.empty(self.H); B = np.empty((self.L, self.H), order="F") if want_B else None
+        SB = np.empty((self.H, self.H), order="F"); cb = np.empty(self.H); dl = np.empty(self.H)
+        sh, ze = C.c_double(), C.c_double()
+        self._chk(self._lib.vbmf_sparse_get_state(self._h, _dptr(a), _dptr(ds), _dptr(ca), _dptr(be), _dptr(sa), _dptr(B),
+                                                  self.L, _dptr(SB), _dptr(cb), _dptr(dl), C.byref(sh), C.byref(ze)))
+        return dict(ATVecHat=a, diagSigmaATVec=ds, CA=ca, beta=be, SigmaA_diag=sa, BHat=B, SigmaB=SB, CB=cb, delta=dl,
+                    sigmaHat=sh.value, zeta=ze.value)
+
+    def sparse_step(self, which):
+        self._chk(self._lib.vbmf_sparse_step(self._h, which))
+
+    def sparse_run(self, niter, eps=1e-6, est_cb=True, want_trace=False):
+        it = C.c_int64(); d = C.c_double()
+        tr = np.zeros((max(niter, 1), 4)) if want_trace else None
+        self._chk(self._lib.vbmf_sparse_run(self._h, niter, eps, int(est_cb), C.byref(it), C.byref(d), _dptr(tr)))
+        return it.value, d.value, (tr[:it.value] if want_trace else None)
+
+    def sparse_lower_bound(self, clamp=True):
+        v = C.c_double()
+        self._chk(self._lib.vbmf_sparse_lower_bound(self._h, int(clamp), C.byref(v)))
         return v.value
 
     # ---- multi-GPU ----

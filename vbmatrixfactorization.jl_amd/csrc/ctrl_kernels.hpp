@@ -239,10 +239,9 @@ __device__ __forceinline__ void eig_dev(double* __restrict__ st, StateLayout lay
     float* A0 = ldsf;
     float* A1 = ldsf + NP * LD;
     const int tx = threadIdx.x % T, ty = threadIdx.x / T;
-    const float inv_tr = (float)(1.0 / tr);
     for (int t = threadIdx.x; t < NP * NP; t += blockDim.x) {
         const int i = t / NP, j = t - i * NP;
-        A0[i * LD + j] = (i < H && j < H) ? (float)(G[(long long)i * Hp + j] * (double)inv_tr) : 0.f;
+        A0[i * LD + j] = (i < H && j < H) ? (float)(G[(long long)i * Hp + j] / tr) : 0.f;   // |G_ij| <= tr: no overflow
     }
     __syncthreads();
     float* cur = A0;

@@ -1,0 +1,244 @@
+// sparse_kernels.hpp -- the ARD-sparse variant (src/vbmf_sparse.jl, full_cov=false, diag_var=false).
+//
+// The two streaming passes (Y'B, Y*A) and the B-side post/Gram kernels are shared with the basic
+// model; what differs is element-wise over the M x H entries of vec(A') plus the H x H control algebra:
+//   sparse_update_a    diagSigma = 1/(v_spread + CA); vec(A') = sigmaHat * diagSigma .* vec(B'Y); mask
+//                      (src/vbmf_sparse.jl:214-232,244-246; QS1 `repeat(v, inner=M-1)` layout, QS2)
+//   sparse_update_ca   beta = beta0 + (A.^2 + diagSigma)/2; CA = alpha ./ beta            (:284-288)
+//   colsum             SigmaA = diag(sum_m diagSigma[m,:])                                 (:236-239)
+//   sparse_cov_b       SigmaB = inv(diag(CB) + sigmaHat (A'A + SigmaA))                    (:263-265)
+//   sparse_ctrl_end    CB/delta (:295-300), zeta/sigmaHat (:317-321), d and the loop test (:389,368)
+//   sparse_lb_sums     the four M*H-long sums lowerBound needs                             (:442-443,453-455,461,467)
+// State block reuse: S_SIGMA2 holds sigmaHat (a PRECISION here), the `ca` strip holds delta, `cb` holds CB.
+#pragma once
+#include "common.hpp"
+#include "ctrl_kernels.hpp"
+
+namespace vbmf {
+
+enum : int { S_ZETA = 12, S_ALPHA = 13, S_GAMMA = 14, S_ETA = 15, S_BETA0 = 16, S_DELTA0 = 17, S_ZETA0 = 18 };
+
+// v[h] = sigmaHat * ||B[:,h]||^2 + L * SigmaB[h,h]   (:217; sigmaHat does NOT multiply L*SigmaB: QS2)
+__global__ void sparse_v_kernel(const double* __restrict__ st, StateLayout lay, int H, double Lg,
+                                double* __restrict__ v) {
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= H) return;
+    const long long hh = (long long)h * lay.Hp + h;
+    v[h] = st[lay.scal() + S_SIGMA2] * st[lay.GB() + hh] + Lg * st[lay.SB() + hh];
+}
+
+// P: [Hp][ldP] fp32 (x fastest); A32/dS32/CA32: [Mp][Hp] fp32 row-major.  compat: QS1 layout.
+__global__ __launch_bounds__(256) void sparse_update_a_kernel(const float* __restrict__ P, long long ldP,
+                                                              const float* __restrict__ CA32,
+                                                              const double* __restrict__ v,
+                                                              const double* __restrict__ st, StateLayout lay,
+                                                              float* __restrict__ A32, float* __restrict__ dS32,
+                                                              const unsigned char* __restrict__ mask, int hmask_start,
+                                                              long long M, int H, int Hp, int compat) {
+    const double sig = st[lay.scal() + S_SIGMA2];
+    const long long total = M * Hp;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long m = i / Hp;
+        const int h = (int)(i - m * Hp);
+        float a = 0.f, ds = 0.f;
+        if (h < H) {
+            const long long p = m * H + h;                         // 0-based position in vec(A')
+            long long vi = h;
+            if (compat) vi = (p < H) ? p : (p - H) / (M - 1);      // repeat(v, inner = M-1) after the first H
+            const double prec = v[vi] + (double)CA32[i];
+            const double d = 1.0 / prec;
+            ds = (float)d;
+            a = (float)(sig * d * (double)P[(long long)h * ldP + m]);
+            if (mask != nullptr && h >= hmask_start && mask[m]) a = 0.f;
+        }
+        A32[i] = a;
+        dS32[i] = ds;
+    }
+}
+
+__global__ __launch_bounds__(256) void sparse_update_ca_kernel(const float* __restrict__ A32,
+                                                               const float* __restrict__ dS32,
+                                                               float* __restrict__ beta32, float* __restrict__ CA32,
+                                                               double alpha, double beta0, long long M, int H, int Hp) {
+    const long long total = M * Hp;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int h = (int)(i % Hp);
+        if (h >= H) continue;
+        const double a = (double)A32[i];
+        const double b = beta0 + 0.5 * (a * a + (double)dS32[i]);
+        beta32[i] = (float)b;
+        CA32[i] = (float)(alpha / b);
+    }
+}
+
+// out[h] = sum_m X[m][h]  (fp64, one block per 32 columns, fixed order)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, long long M, int H, int Hp,
+                                                     double* __restrict__ st, StateLayout lay) {
+    __shared__ double sh[8][32];
+    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int h = blockIdx.x * 32 + c;
+    double a = 0.0;
+    if (h < H)
+        for (long long m = g; m < M; m += 8) a += (double)X[m * Hp + h];
+    sh[g][c] = a;
+    __syncthreads();
+    if (g == 0 && h < Hp) {
+        double s = 0.0;
+        for (int q = 0; q < 8; ++q) s += sh[q][c];
+        // SigmaA is diagonal here: write the full row so stale off-diagonals never survive
+        for (int j = 0; j < Hp; ++j) st[lay.SA() + (long long)h * Hp + j] = (j == h && h < H) ? s : 0.0;
+    }
+}
+
+// SigmaB = inv(diag(CB) + sigmaHat*(GA + SigmaA));  S32 = sigmaHat*SigmaB;  KB = K/sigmaHat (so that
+// B = Q*S32 gives tr(B'Q) = tr(KB * B'B), the identity the basic model uses too).
+template <int R, int T>
+__global__ __launch_bounds__(T * T) void sparse_cov_b_kernel(double* __restrict__ st, StateLayout lay, int H,
+                                                             float* __restrict__ S32, int* __restrict__ ints) {
+    extern __shared__ __attribute__((aligned(16))) double lds_scb[];
+    __shared__ double red[16];
+    if (load_stop(ints)) return;
+    constexpr int NP = T * R;
+    const int Hp = lay.Hp;
+    const int tx = threadIdx.x % T, ty = threadIdx.x / T;
+    double* scal = st + lay.scal();
+    const double sig = scal[S_SIGMA2];
+    const double* cb = st + lay.cb();
+    double w[R][R];
+#pragma unroll
+    for (int a = 0; a < R; ++a)
+#pragma unroll
+        for (int b = 0; b < R; ++b) {
+            const int i = ty + T * a, j = tx + T * b;
+            double v = (i == j) ? 1.0 : 0.0;
+            if (i < H && j < H) {
+                v = sig * (st[lay.GA() + (long long)i * Hp + j] + st[lay.SA() + (long long)i * Hp + j]);
+                if (i == j) v += cb[i];
+                st[lay.KB() + (long long)i * Hp + j] = v / sig;
+            }
+            w[a][b] = v;
+        }
+    double* strip = lds_scb;
+    double* pivs = lds_scb + 4 * NP;
+    gj_tiled<R, T>(w, H, strip, pivs);
+#pragma unroll
+    for (int a = 0; a < R; ++a)
+#pragma unroll
+        for (int b = 0; b < R; ++b) {
+            const int i = ty + T * a, j = tx + T * b;
+            if (i < Hp && j < Hp) {
+                const double v = (i < H && j < H) ? w[a][b] : 0.0;
+                st[lay.SB() + (long long)i * Hp + j] = v;
+                S32[(long long)i * Hp + j] = (float)(sig * v);
+            }
+        }
+    __syncthreads();
+    double ld = 0.0;
+    int bad = 0;
+    for (int k = threadIdx.x; k < H; k += blockDim.x) {
+        const double pv = pivs[k];
+        if (!(pv > 0.0) || !isfinite(pv)) bad = 1;
+        ld += log(pv);
+    }
+    ld = block_sum(ld, red);
+    if (bad) atomicExch(ints + I_ERR, 1);
+    if (threadIdx.x == 0) scal[S_LOGDET_SB] = -ld;          // log det SigmaB
+}
+
+// flags: bit1 est_cb -> CB/delta, bit2 sigma update, bit3 d + loop bookkeeping, bit4 tr(B'Q) from the identity
+__global__ __launch_bounds__(256) void sparse_ctrl_end_kernel(double* __restrict__ st, StateLayout lay, int H,
+                                                              double Lg, int flags, double eps,
+                                                              double* __restrict__ trace, int* __restrict__ ints) {
+    __shared__ double red[16];
+    if (load_stop(ints)) return;
+    const int Hp = lay.Hp;
+    const double* GA = st + lay.GA();
+    const double* GB = st + lay.GB();
+    const double* SA = st + lay.SA();
+    const double* SB = st + lay.SB();
+    const double* KB = st + lay.KB();
+    double* delta = st + lay.ca();
+    double* cb = st + lay.cb();
+    double* scal = st + lay.scal();
+    double t1 = 0.0, t2 = 0.0;
+    for (int t = threadIdx.x; t < H * H; t += blockDim.x) {
+        const int i = t / H, j = t - i * H;
+        const long long ij = (long long)i * Hp + j;
+        t1 += KB[ij] * GB[ij];
+        t2 += (GA[ij] + SA[ij]) * (GB[ij] + Lg * SB[ij]);        // SigmaA already summed over m (QS3)
+    }
+    t1 = block_sum(t1, red);
+    t2 = block_sum(t2, red);
+    __syncthreads();
+    if (flags & 2)
+        for (int h = threadIdx.x; h < H; h += blockDim.x) {
+            const long long hh = (long long)h * Hp + h;
+            const double dl = scal[S_DELTA0] + 0.5 * GB[hh] + 0.5 * SB[hh];    // :297
+            delta[h] = dl;
+            cb[h] = scal[S_GAMMA] / dl;                                         // :298
+        }
+    if (threadIdx.x == 0) {
+        const double trBQ = (flags & 16) ? t1 : scal[S_TRDOT];
+        scal[S_TRYBA] = trBQ;
+        if (flags & 4) {
+            const double zeta = scal[S_ZETA0] + 0.5 * scal[S_TRYY] - trBQ + 0.5 * t2;   // :317-319
+            scal[S_ZETA] = zeta;
+            scal[S_SIGMA2] = scal[S_ETA] / zeta;                                         // :321
+        }
+        if (flags & 8) {
+            const double d = sqrt(scal[S_LAMD] / scal[S_LAMB_PREV]);
+            scal[S_D] = d;
+            scal[S_LAMB_PREV] = scal[S_LAMB_NEW];
+            const int it = ints[I_ITERS];
+            if (trace) { trace[4 * it + 0] = d; trace[4 * it + 1] = scal[S_SIGMA2]; trace[4 * it + 2] = 0.0; trace[4 * it + 3] = scal[S_ZETA]; }
+            ints[I_ITERS] = it + 1;
+            if (!(d > eps) || it + 1 >= ints[I_NITER])
+                __hip_atomic_store(ints + I_STOP, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// out[0..3] += [ sum log(beta), sum CA*(A^2 + dS), sum CA, sum log(dS) ] over the valid M x H entries
+__global__ __launch_bounds__(256) void sparse_lb_sums_kernel(const float* __restrict__ A32, const float* __restrict__ dS32,
+                                                             const float* __restrict__ CA32, const float* __restrict__ beta32,
+                                                             long long M, int H, int Hp, double* __restrict__ partials) {
+    __shared__ double sh[4][4];
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    const long long total = M * Hp;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        if ((int)(i % Hp) >= H) continue;
+        const double a = A32[i], ds = dS32[i], ca = CA32[i], be = beta32[i];
+        s0 += log(be); s1 += ca * (a * a + ds); s2 += ca; s3 += log(ds);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        s0 += __shfl_down(s0, off); s1 += __shfl_down(s1, off); s2 += __shfl_down(s2, off); s3 += __shfl_down(s3, off);
+    }
+    if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; sh[w][0] = s0; sh[w][1] = s1; sh[w][2] = s2; sh[w][3] = s3; }
+    __syncthreads();
+    if (threadIdx.x < 4)
+        partials[(long long)blockIdx.x * 4 + threadIdx.x] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+}
+
+// vec(A') (index m*H + h, fp64 host order) <-> [Mp][Hp] fp32
+__global__ void pack_vec_kernel(const double* __restrict__ src, long long M, int H, int Hp, long long Mp,
+                                float* __restrict__ dst, float fill) {
+    const long long total = Mp * Hp;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long m = i / Hp; const int h = (int)(i % Hp);
+        dst[i] = (m < M && h < H) ? (float)src[m * H + h] : fill;
+    }
+}
+__global__ void unpack_vec_kernel(const float* __restrict__ src, long long M, int H, int Hp, double* __restrict__ dst) {
+    const long long total = M * H;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long m = i / H; const int h = (int)(i % H);
+        dst[i] = (double)src[m * Hp + h];
+    }
+}
+
+}  // namespace vbmf

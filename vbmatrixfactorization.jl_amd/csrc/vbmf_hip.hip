@@ -33,6 +33,7 @@
 #include "ctrl_kernels.hpp"
 #include "post_kernels.hpp"
 #include "rng.hpp"
+#include "sparse_kernels.hpp"
 #include "stream_gemm.hpp"
 #include "tile_kernels.hpp"
 
@@ -59,6 +60,12 @@ struct vbmf_ctx {
     double* st = nullptr;
     double* gtmp = nullptr;          // 2*Hp^2 local Gram sums (all-reduce staging)
     double* ypart = nullptr;         // per-block partials of ||Y||^2 (fixed-order sum)
+    // ARD-sparse variant (src/vbmf_sparse.jl, diagonal branch)
+    bool sparse = false;
+    float *dS32 = nullptr, *CA32 = nullptr, *beta32 = nullptr;   // diagSigmaATVec, CA, beta as [Mp][Hp]
+    double* vtab = nullptr;          // v[h] of src/vbmf_sparse.jl:217
+    vbmf_sparse_hyper hyp{};
+    double alpha = 0, gamma_ = 0, eta = 0;
     StateLayout lay{};
     int* ints = nullptr;
     int* ints_host = nullptr;        // pinned
@@ -545,7 +552,7 @@ int vbmf_destroy(vbmf_ctx* c) {
     prof_harvest(c);
     if (c->comm) ncclCommDestroy(c->comm);
     void* bufs[] = {c->Y1, c->Y2, c->FA, c->FB, c->P, c->Q, c->Pred, c->A32, c->B32[0], c->B32[1], c->SA32,
-                    c->SB32, c->gslab, c->st, c->gtmp, c->ypart, c->ints, c->mask};
+                    c->SB32, c->gslab, c->st, c->gtmp, c->ypart, c->ints, c->mask, c->dS32, c->CA32, c->beta32, c->vtab};
     for (void* b : bufs) if (b) hipFree(b);
     if (c->ints_host) hipHostFree(c->ints_host);
     if (c->scal_host) hipHostFree(c->scal_host);
@@ -567,7 +574,9 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
     }
     if (L <= 0 || M <= 0 || H <= 0) { c->err = "L, M, H must be positive"; return bail(VBMF_ERR_INVALID); }
     if (H > 256) { c->err = "H > 256 is not supported"; return bail(VBMF_ERR_UNSUPPORTED); }
-    if (c->o.variant != VBMF_VARIANT_BASIC) { c->err = "only the basic variant is built in this round"; return bail(VBMF_ERR_UNSUPPORTED); }
+    if (c->o.variant != VBMF_VARIANT_BASIC && c->o.variant != VBMF_VARIANT_SPARSE_DIAG) { c->err = "unknown variant"; return bail(VBMF_ERR_INVALID); }
+    c->sparse = (c->o.variant == VBMF_VARIANT_SPARSE_DIAG);
+    if (c->sparse && opts && opts->nranks > 1) { c->err = "the sparse variant is single-GPU in this round"; return bail(VBMF_ERR_UNSUPPORTED); }
     if (c->o.nranks < 1 || c->o.rank < 0 || c->o.rank >= c->o.nranks) { c->err = "bad nranks/rank"; return bail(VBMF_ERR_INVALID); }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -639,6 +648,12 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
     ALLOC(c->ypart, (size_t)16384 * 8);
     ALLOC(c->ints, 16 * sizeof(int));
     ALLOC(c->mask, (size_t)c->Mp);
+    if (c->sparse) {
+        ALLOC(c->dS32, (size_t)c->Mp * c->Hp * 4);
+        ALLOC(c->CA32, (size_t)c->Mp * c->Hp * 4);
+        ALLOC(c->beta32, (size_t)c->Mp * c->Hp * 4);
+        ALLOC(c->vtab, (size_t)c->Hp * 8);
+    }
 #undef ALLOC
     if (hipHostMalloc((void**)&c->ints_host, 16 * sizeof(int)) != hipSuccess ||
         hipHostMalloc((void**)&c->scal_host, 32 * sizeof(double)) != hipSuccess) {
@@ -821,6 +836,7 @@ int vbmf_set_state(vbmf_ctx* c, const double* AHat, int64_t ldA, const double* B
                    const double* SigmaA, const double* SigmaB, const double* CA_diag, const double* CB_diag,
                    double sigma2, const int64_t* labels0, int64_t nlabels, int64_t H1) {
     if (!c) return VBMF_ERR_INVALID;
+    if (c->sparse) FAIL(c, VBMF_ERR_INVALID, "sparse context: use vbmf_sparse_set_state");
     if (!AHat || !BHat || !SigmaA || !SigmaB || !CA_diag || !CB_diag) FAIL(c, VBMF_ERR_INVALID, "vbmf_set_state: null pointer");
     if (ldA < c->M || ldB < c->L) FAIL(c, VBMF_ERR_INVALID, "vbmf_set_state: leading dimension too small");
     if (H1 < 0 || H1 > c->H || nlabels < 0 || (nlabels > 0 && !labels0)) FAIL(c, VBMF_ERR_INVALID, "vbmf_set_state: bad H1/labels");
@@ -886,6 +902,7 @@ int vbmf_get_state(vbmf_ctx* c, double* AHat, int64_t ldA, double* BHat, int64_t
 // ---- updates -----------------------------------------------------------------------------------
 int vbmf_step(vbmf_ctx* c, int which) {
     if (!c) return VBMF_ERR_INVALID;
+    if (c->sparse) FAIL(c, VBMF_ERR_INVALID, "sparse context: use vbmf_sparse_step");
     if (which & ~31) FAIL(c, VBMF_ERR_INVALID, "vbmf_step: unknown update bits");
     HIPCHK(c, hipSetDevice(c->o.device));
     TRY(ensure_ready(c));
@@ -911,6 +928,7 @@ int vbmf_step(vbmf_ctx* c, int which) {
 int vbmf_run(vbmf_ctx* c, int64_t niter, double eps, int est_covs, int est_var, int64_t* iters_done,
              double* d_last, double* trace) {
     if (!c) return VBMF_ERR_INVALID;
+    if (c->sparse) FAIL(c, VBMF_ERR_INVALID, "sparse context: use vbmf_sparse_run");
     if (niter < 0 || niter > (1ll << 30)) FAIL(c, VBMF_ERR_INVALID, "vbmf_run: bad niter");
     HIPCHK(c, hipSetDevice(c->o.device));
     TRY(ensure_ready(c));
@@ -1113,6 +1131,351 @@ int vbmf_device_sync(vbmf_ctx* c) {
     if (!c) return VBMF_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->o.device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return VBMF_OK;
+}
+
+
+// ================================================================================================
+// ARD-sparse variant (src/vbmf_sparse.jl, full_cov=false, diag_var=false)
+// ================================================================================================
+}  // extern "C"
+
+static double digamma_host(double x) {
+    double r = 0.0;
+    while (x < 10.0) { r -= 1.0 / x; x += 1.0; }
+    const double f = 1.0 / (x * x);
+    return r + std::log(x) - 0.5 / x -
+           f * (1.0 / 12 - f * (1.0 / 120 - f * (1.0 / 252 - f * (1.0 / 240 - f * (5.0 / 660 - f * (691.0 / 32760))))));
+}
+
+template <int R, int T>
+static void launch_scov_t(vbmf_ctx* c) {
+    const size_t lds = (size_t)(5 * T * R) * sizeof(double);
+    hipLaunchKernelGGL((sparse_cov_b_kernel<R, T>), dim3(1), dim3(T * T), lds, c->stream, c->st, c->lay, (int)c->H, c->SB32, c->ints);
+}
+static int launch_sparse_cov_b(vbmf_ctx* c) {
+    const int H = (int)c->H;
+    if (H <= 16) launch_scov_t<1, 16>(c);
+    else if (H <= 32) launch_scov_t<2, 16>(c);
+    else if (H <= 64) launch_scov_t<4, 16>(c);
+    else if (H <= 128) launch_scov_t<8, 16>(c);
+    else launch_scov_t<8, 32>(c);
+    HIPCHK(c, hipGetLastError());
+    return VBMF_OK;
+}
+
+static int sparse_colsum(vbmf_ctx* c) {
+    hipLaunchKernelGGL(colsum_kernel, dim3(c->Hp / 32), dim3(256), 0, c->stream, c->dS32, (long long)c->M, (int)c->H, c->Hp, c->st, c->lay);
+    HIPCHK(c, hipGetLastError());
+    return VBMF_OK;
+}
+
+static int do_sparse_update_A(vbmf_ctx* c) {
+    TRY(ensure_gram_B(c));
+    hipLaunchKernelGGL(sparse_v_kernel, dim3((c->Hp + 63) / 64), dim3(64), 0, c->stream, c->st, c->lay, (int)c->H, (double)c->Lg, c->vtab);
+    TRY(launch_stream(c, 0));
+    const long long n = (long long)c->Hp * c->d1.XT * 32;
+    hipLaunchKernelGGL(slab_sum_kernel, dim3(grid_for(n / 4, 256, 2048)), dim3(256), 0, c->stream, c->P, c->d1.nsplit, n, c->Pred, n, c->ints + I_STOP);
+    const int compat = (c->o.reference_compat & VBMF_COMPAT_SPARSE_REPEAT) ? 1 : 0;
+    if (compat && c->M < 2) FAIL(c, VBMF_ERR_INVALID, "repeat(v, inner=M-1) needs M >= 2");
+    hipLaunchKernelGGL(sparse_update_a_kernel, dim3(grid_for((int64_t)c->M * c->Hp)), dim3(256), 0, c->stream, c->Pred,
+                       (long long)c->d1.XT * 32, c->CA32, c->vtab, c->st, c->lay, c->A32, c->dS32,
+                       c->has_mask ? c->mask : nullptr, (int)(c->H - c->H1), (long long)c->M, (int)c->H, c->Hp, compat);
+    HIPCHK(c, hipGetLastError());
+    TRY(launch_retile(c, 0));                       // operand tiles; A32 := the value the tiles encode
+    TRY(launch_gram(c, 0, c->A32, nullptr, false));
+    TRY(sparse_colsum(c));                          // SigmaA = diag(sum_m diagSigma)
+    c->gA_valid = true;
+    c->P_valid = true;
+    c->kb_identity = false;
+    return VBMF_OK;
+}
+
+static int do_sparse_update_B(vbmf_ctx* c) {
+    TRY(ensure_gram_A(c));
+    TRY(launch_sparse_cov_b(c));
+    TRY(launch_stream(c, 1));
+    if (fused_gram(c)) {
+        TRY(launch_post_gram(c, 1, c->Q, c->d2.nsplit));
+    } else {
+        TRY(launch_post(c, 1, c->Q, c->d2.nsplit));
+        TRY(launch_gram(c, 1, c->B32[c->bcur ^ 1], c->B32[c->bcur], false));
+    }
+    c->bcur ^= 1;
+    c->gB_valid = true;
+    c->P_valid = false;
+    c->kb_identity = true;
+    return VBMF_OK;
+}
+
+static int sparse_update_CA(vbmf_ctx* c) {
+    hipLaunchKernelGGL(sparse_update_ca_kernel, dim3(grid_for((int64_t)c->M * c->Hp)), dim3(256), 0, c->stream, c->A32, c->dS32,
+                       c->beta32, c->CA32, c->alpha, c->hyp.beta0, (long long)c->M, (int)c->H, c->Hp);
+    HIPCHK(c, hipGetLastError());
+    return VBMF_OK;
+}
+
+static int launch_sparse_ctrl_end(vbmf_ctx* c, int flags, double eps, double* trace) {
+    hipLaunchKernelGGL(sparse_ctrl_end_kernel, dim3(1), dim3(256), 0, c->stream, c->st, c->lay, (int)c->H, (double)c->Lg, flags, eps, trace, c->ints);
+    HIPCHK(c, hipGetLastError());
+    return VBMF_OK;
+}
+
+static int upload_vec(vbmf_ctx* c, const double* src, float* dst, float fill) {
+    double* tmp = nullptr;
+    const size_t n = (size_t)c->M * c->H;
+    HIPCHK(c, hipMalloc((void**)&tmp, n * 8));
+    hipError_t e = hipMemcpyAsync(tmp, src, n * 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(pack_vec_kernel, dim3(grid_for(c->Mp * c->Hp)), dim3(256), 0, c->stream, tmp, (long long)c->M, (int)c->H, c->Hp, (long long)c->Mp, dst, fill);
+        e = hipStreamSynchronize(c->stream);
+    }
+    hipFree(tmp);
+    if (e != hipSuccess) FAIL(c, VBMF_ERR_HIP, "vec upload failed: %s", hipGetErrorString(e));
+    return VBMF_OK;
+}
+static int download_vec(vbmf_ctx* c, const float* src, double* dst) {
+    double* tmp = nullptr;
+    const size_t n = (size_t)c->M * c->H;
+    HIPCHK(c, hipMalloc((void**)&tmp, n * 8));
+    hipLaunchKernelGGL(unpack_vec_kernel, dim3(grid_for((int64_t)n)), dim3(256), 0, c->stream, src, (long long)c->M, (int)c->H, c->Hp, tmp);
+    hipError_t e = hipMemcpyAsync(dst, tmp, n * 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(tmp);
+    if (e != hipSuccess) FAIL(c, VBMF_ERR_HIP, "vec download failed: %s", hipGetErrorString(e));
+    return VBMF_OK;
+}
+
+extern "C" {
+
+int vbmf_sparse_set_state(vbmf_ctx* c, const double* ATVecHat, const double* diagSigmaATVec, const double* CA,
+                          const double* beta, const double* BHat, int64_t ldB, const double* SigmaB,
+                          const double* CB, const double* delta, double sigmaHat, double zeta,
+                          const vbmf_sparse_hyper* hyper, const int64_t* labels0, int64_t nlabels, int64_t H1) {
+    if (!c) return VBMF_ERR_INVALID;
+    if (!c->sparse) FAIL(c, VBMF_ERR_INVALID, "not a sparse context (opts.variant)");
+    if (!ATVecHat || !diagSigmaATVec || !CA || !beta || !BHat || !SigmaB || !CB || !delta || !hyper)
+        FAIL(c, VBMF_ERR_INVALID, "vbmf_sparse_set_state: null pointer");
+    if (ldB < c->L) FAIL(c, VBMF_ERR_INVALID, "ldB < L");
+    if (H1 < 0 || H1 > c->H || nlabels < 0 || (nlabels > 0 && !labels0)) FAIL(c, VBMF_ERR_INVALID, "bad H1/labels");
+    if (!(sigmaHat > 0.0)) FAIL(c, VBMF_ERR_INVALID, "sigmaHat must be positive");
+    for (int64_t h = 0; h < c->H; ++h) if (!(CB[h] > 0.0)) FAIL(c, VBMF_ERR_INVALID, "CB must be positive");
+    HIPCHK(c, hipSetDevice(c->o.device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->hyp = *hyper;
+    c->alpha = hyper->alpha0 + 0.5;                                   // src/vbmf_sparse.jl:131
+    c->gamma_ = hyper->gamma0 + 0.5 * (double)c->Lg;                  // :137
+    c->eta = hyper->eta0 + 0.5 * (double)c->Lg * (double)c->M;        // :143
+    c->bcur = 0;
+    TRY(upload_vec(c, ATVecHat, c->A32, 0.f));
+    TRY(upload_vec(c, diagSigmaATVec, c->dS32, 0.f));
+    TRY(upload_vec(c, CA, c->CA32, 1.f));
+    TRY(upload_vec(c, beta, c->beta32, 1.f));
+    TRY(upload_factor(c, BHat, ldB, c->L, c->Lp, c->B32[0]));
+    TRY(upload_small(c, SigmaB, c->lay.SB(), true));
+    TRY(upload_small(c, CB, c->lay.cb(), false));
+    TRY(upload_small(c, delta, c->lay.ca(), false));
+    double sc[32];
+    HIPCHK(c, hipMemcpy(sc, c->st + c->lay.scal(), sizeof sc, hipMemcpyDeviceToHost));
+    sc[S_SIGMA2] = sigmaHat; sc[S_ZETA] = zeta; sc[S_ALPHA] = c->alpha; sc[S_GAMMA] = c->gamma_; sc[S_ETA] = c->eta;
+    sc[S_BETA0] = hyper->beta0; sc[S_DELTA0] = hyper->delta0; sc[S_ZETA0] = hyper->zeta0;
+    HIPCHK(c, hipMemcpy(c->st + c->lay.scal(), sc, sizeof sc, hipMemcpyHostToDevice));
+    std::vector<unsigned char> mk((size_t)c->Mp, 0);
+    for (int64_t i = 0; i < nlabels; ++i) {
+        if (labels0[i] < 0 || labels0[i] >= c->M) FAIL(c, VBMF_ERR_INVALID, "label out of range");
+        mk[(size_t)labels0[i]] = 1;
+    }
+    HIPCHK(c, hipMemcpy(c->mask, mk.data(), mk.size(), hipMemcpyHostToDevice));
+    c->H1 = H1;
+    c->has_mask = (nlabels > 0 && H1 > 0);
+    TRY(launch_retile(c, 0));
+    TRY(launch_retile(c, 1));
+    TRY(sparse_colsum(c));
+    const int H = (int)c->H;
+    const size_t need = ((size_t)H * H + 2 * H) * sizeof(double);
+    const int use_lds = need <= 60 * 1024;
+    hipLaunchKernelGGL(logdet_kernel, dim3(1), dim3(ctrl_threads(H)), use_lds ? need : 0, c->stream, c->st, c->lay, H, 1, use_lds);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemsetAsync(c->ints, 0, 16 * sizeof(int), c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->gA_valid = c->gB_valid = c->P_valid = c->kb_identity = false;
+    c->haveState = true;
+    return VBMF_OK;
+}
+
+int vbmf_sparse_get_state(vbmf_ctx* c, double* ATVecHat, double* diagSigmaATVec, double* CA, double* beta,
+                          double* SigmaA_diag, double* BHat, int64_t ldB, double* SigmaB, double* CB,
+                          double* delta, double* sigmaHat, double* zeta) {
+    if (!c) return VBMF_ERR_INVALID;
+    if (!c->sparse || !c->haveState) FAIL(c, VBMF_ERR_INVALID, "no sparse state");
+    HIPCHK(c, hipSetDevice(c->o.device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (ATVecHat) TRY(download_vec(c, c->A32, ATVecHat));
+    if (diagSigmaATVec) TRY(download_vec(c, c->dS32, diagSigmaATVec));
+    if (CA) TRY(download_vec(c, c->CA32, CA));
+    if (beta) TRY(download_vec(c, c->beta32, beta));
+    if (BHat) { if (ldB < c->L) FAIL(c, VBMF_ERR_INVALID, "ldB < L"); TRY(download_factor(c, c->B32[c->bcur], c->L, BHat, ldB)); }
+    std::vector<double> buf((size_t)c->lay.total());
+    HIPCHK(c, hipMemcpy(buf.data(), c->st, buf.size() * 8, hipMemcpyDeviceToHost));
+    for (int64_t h = 0; h < c->H; ++h) {
+        if (SigmaA_diag) SigmaA_diag[h] = buf[(size_t)c->lay.SA() + (size_t)h * c->Hp + h];
+        if (CB) CB[h] = buf[(size_t)c->lay.cb() + h];
+        if (delta) delta[h] = buf[(size_t)c->lay.ca() + h];
+    }
+    if (SigmaB)
+        for (int64_t j = 0; j < c->H; ++j)
+            for (int64_t i = 0; i < c->H; ++i) SigmaB[i + j * c->H] = buf[(size_t)c->lay.SB() + (size_t)i * c->Hp + j];
+    if (sigmaHat) *sigmaHat = buf[(size_t)c->lay.scal() + S_SIGMA2];
+    if (zeta) *zeta = buf[(size_t)c->lay.scal() + S_ZETA];
+    return VBMF_OK;
+}
+
+int vbmf_sparse_step(vbmf_ctx* c, int which) {
+    if (!c) return VBMF_ERR_INVALID;
+    if (!c->sparse) FAIL(c, VBMF_ERR_INVALID, "not a sparse context");
+    if (which & ~31) FAIL(c, VBMF_ERR_INVALID, "vbmf_sparse_step: unknown update bits");
+    HIPCHK(c, hipSetDevice(c->o.device));
+    TRY(ensure_ready(c));
+    if (which & VBMF_SSTEP_A) TRY(do_sparse_update_A(c));
+    if (which & VBMF_SSTEP_B) TRY(do_sparse_update_B(c));
+    if (which & VBMF_SSTEP_CA) TRY(sparse_update_CA(c));
+    int flags = 0;
+    if (which & VBMF_SSTEP_CB) { TRY(ensure_gram_B(c)); flags |= 2; }
+    if (which & VBMF_SSTEP_SIGMA) {
+        TRY(ensure_gram_A(c));
+        TRY(ensure_gram_B(c));
+        int f = 0;
+        TRY(prepare_trYBA(c, &f));
+        flags |= 4 | f;
+    }
+    if (flags) TRY(launch_sparse_ctrl_end(c, flags, 0.0, nullptr));
+    return check_device_err(c);
+}
+
+int vbmf_sparse_run(vbmf_ctx* c, int64_t niter, double eps, int est_cb, int64_t* iters_done, double* d_last,
+                    double* trace) {
+    if (!c) return VBMF_ERR_INVALID;
+    if (!c->sparse) FAIL(c, VBMF_ERR_INVALID, "not a sparse context");
+    if (niter < 0 || niter > (1ll << 30)) FAIL(c, VBMF_ERR_INVALID, "bad niter");
+    HIPCHK(c, hipSetDevice(c->o.device));
+    TRY(ensure_ready(c));
+    if (iters_done) *iters_done = 0;
+    if (d_last) *d_last = eps + 1.0;                      // src/vbmf_sparse.jl:364
+    if (niter == 0) return VBMF_OK;
+    double* trace_dev = nullptr;
+    if (trace) {
+        HIPCHK(c, hipMalloc((void**)&trace_dev, (size_t)niter * 4 * 8));
+        HIPCHK(c, hipMemsetAsync(trace_dev, 0, (size_t)niter * 4 * 8, c->stream));
+    }
+    int init[4] = {0, 0, 0, (int)niter};
+    HIPCHK(c, hipMemcpyAsync(c->ints, init, sizeof init, hipMemcpyHostToDevice, c->stream));
+    int rc = ensure_gram_B(c);
+    if (rc == VBMF_OK) rc = launch_eig(c, 0, 1);
+    if (rc == VBMF_OK)
+        hipLaunchKernelGGL(copy_scalar_kernel, dim3(1), dim3(1), 0, c->stream, c->st, c->lay, (int)S_LAMB_PREV, (int)S_LAMB_NEW);
+    const int flags = (est_cb ? 2 : 0) | 4 | 8 | 16;
+    const int bstart = c->bcur;
+    int64_t it = 0;
+    bool stopped = false;
+    while (rc == VBMF_OK && it < niter && !stopped) {
+        rc = do_sparse_update_A(c);
+        if (rc == VBMF_OK) rc = do_sparse_update_B(c);
+        if (rc == VBMF_OK) rc = sparse_update_CA(c);
+        if (rc == VBMF_OK) rc = launch_eig(c, 1, 1);
+        if (rc == VBMF_OK) rc = launch_sparse_ctrl_end(c, flags, eps, trace_dev);
+        ++it;
+        if (rc == VBMF_OK && (it % 8 == 0 || it == niter)) {
+            hipError_t e = hipMemcpyAsync(c->ints_host, c->ints, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) { c->err = std::string("sparse run sync: ") + hipGetErrorString(e); rc = VBMF_ERR_HIP; break; }
+            if (c->ints_host[I_STOP] || c->ints_host[I_ERR]) stopped = true;
+        }
+    }
+    hipStreamSynchronize(c->stream);
+    if (rc == VBMF_OK) {
+        hipError_t e = hipMemcpy(c->ints_host, c->ints, 4 * sizeof(int), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(c->scal_host, c->st + c->lay.scal(), 32 * 8, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { c->err = "sparse run readback failed"; rc = VBMF_ERR_HIP; }
+    }
+    if (rc == VBMF_OK) {
+        const int done = c->ints_host[I_ITERS];
+        c->bcur = bstart ^ (done & 1);
+        if (iters_done) *iters_done = done;
+        if (d_last && done > 0) *d_last = c->scal_host[S_D];
+        if (trace && done > 0 && hipMemcpy(trace, trace_dev, (size_t)done * 4 * 8, hipMemcpyDeviceToHost) != hipSuccess) { c->err = "trace copy failed"; rc = VBMF_ERR_HIP; }
+        if (c->ints_host[I_ERR]) { c->err = "non-positive or non-finite pivot while inverting the posterior precision of B"; rc = VBMF_ERR_NUMERIC; }
+    }
+    int zero4[4] = {0, 0, 0, 0};
+    hipMemcpy(c->ints, zero4, sizeof zero4, hipMemcpyHostToDevice);
+    if (trace_dev) hipFree(trace_dev);
+    c->gA_valid = c->gB_valid = true;
+    c->P_valid = false;
+    c->kb_identity = true;
+    return rc;
+}
+
+int vbmf_sparse_lower_bound(vbmf_ctx* c, int clamp, double* lb) {
+    if (!c || !lb) return VBMF_ERR_INVALID;
+    if (!c->sparse) FAIL(c, VBMF_ERR_INVALID, "not a sparse context");
+    HIPCHK(c, hipSetDevice(c->o.device));
+    TRY(ensure_ready(c));
+    TRY(ensure_gram_A(c));
+    TRY(ensure_gram_B(c));
+    int f = 0;
+    TRY(prepare_trYBA(c, &f));
+    TRY(launch_sparse_ctrl_end(c, f, 0.0, nullptr));       // no updates: stores tr(B'YA) in S_TRYBA
+    const int nb = 256;
+    hipLaunchKernelGGL(sparse_lb_sums_kernel, dim3(nb), dim3(256), 0, c->stream, c->A32, c->dS32, c->CA32, c->beta32,
+                       (long long)c->M, (int)c->H, c->Hp, c->ypart);
+    HIPCHK(c, hipGetLastError());
+    std::vector<double> part((size_t)nb * 4), buf((size_t)c->lay.total());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(part.data(), c->ypart, part.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(buf.data(), c->st, buf.size() * 8, hipMemcpyDeviceToHost));
+    double s_logbeta = 0, s_caq = 0, s_ca = 0, s_logds = 0;
+    for (int b = 0; b < nb; ++b) { s_logbeta += part[4 * b]; s_caq += part[4 * b + 1]; s_ca += part[4 * b + 2]; s_logds += part[4 * b + 3]; }
+    const double* sc = buf.data() + c->lay.scal();
+    const double L = (double)c->Lg, M = (double)c->M, H = (double)c->H, MH = M * H;
+    const double LN2PI = std::log(2.0 * M_PI);
+    const double sig = sc[S_SIGMA2], zeta = sc[S_ZETA], trYY = sc[S_TRYY], trBQ = sc[S_TRYBA];
+    auto at = [&](long long off, int i, int j) { return buf[(size_t)off + (size_t)i * c->Hp + j]; };
+    double t2 = 0, cbq = 0, sumcb = 0, sumlogdelta = 0;
+    for (int i = 0; i < c->H; ++i) {
+        for (int j = 0; j < c->H; ++j)
+            t2 += (at(c->lay.GA(), i, j) + at(c->lay.SA(), i, j)) * (at(c->lay.GB(), i, j) + L * at(c->lay.SB(), i, j));
+        const double cb = buf[(size_t)c->lay.cb() + i];
+        cbq += cb * (at(c->lay.GB(), i, i) + L * at(c->lay.SB(), i, i));
+        sumcb += cb;
+        sumlogdelta += std::log(buf[(size_t)c->lay.ca() + i]);
+    }
+    const vbmf_sparse_hyper& hp = c->hyp;
+    const double eln_sig = digamma_host(c->eta) - std::log(zeta);
+    const double s_eln_ca = MH * digamma_host(c->alpha) - s_logbeta;
+    const double s_eln_cb = H * digamma_host(c->gamma_) - sumlogdelta;
+    double Lb = 0.0;
+    Lb += -L * M / 2 * LN2PI + L * M / 2 * eln_sig;                                        // :438
+    Lb += -sig / 2 * (trYY - 2 * trBQ + t2);                                               // :439-440
+    Lb += -MH / 2 * LN2PI + 0.5 * s_eln_ca;                                                // :442
+    Lb += -0.5 * s_caq;                                                                    // :443
+    Lb += -L * H / 2 * LN2PI;                                                              // :445
+    Lb += L / 2 * s_eln_cb;                                                                // :446
+    Lb += -0.5 * cbq;                                                                      // :447
+    Lb += hp.eta0 * std::log(hp.zeta0) - std::lgamma(hp.eta0);                             // :449
+    Lb += (hp.eta0 - 1) * eln_sig - hp.zeta0 * sig;                                        // :450
+    Lb += MH * (hp.alpha0 * std::log(hp.beta0) - std::lgamma(hp.alpha0));                  // :452
+    Lb += (hp.alpha0 - 1) * s_eln_ca;                                                      // :453
+    Lb += -hp.beta0 * s_ca;                                                                // :454
+    Lb += H * (hp.gamma0 * std::log(hp.delta0) - std::lgamma(hp.gamma0));                  // :456
+    Lb += (hp.gamma0 - 1) * s_eln_cb;                                                      // :457
+    Lb += -hp.gamma0 * sumcb;                                                              // :458 (sic: gamma0)
+    Lb += MH / 2 + MH / 2 * LN2PI + 0.5 * s_logds;                                         // :461 normalEntropy(diag)
+    double logdet_kron = L * sc[S_LOGDET_SB];                                              // det(kron(SigmaB, I_L)) = det(SigmaB)^L
+    if (clamp) logdet_kron = std::max(logdet_kron, std::log(4.9406564584124654e-324));     // src/util.jl:118-122
+    Lb += L * H / 2 + L * H / 2 * LN2PI + 0.5 * logdet_kron;                               // :463
+    Lb += c->eta + std::log(zeta) + std::lgamma(c->eta) + (1 - c->eta) * digamma_host(c->eta);               // :465
+    Lb += MH * (c->alpha + std::lgamma(c->alpha) + (1 - c->alpha) * digamma_host(c->alpha)) + s_logbeta;     // :467
+    Lb += H * (c->gamma_ + std::lgamma(c->gamma_) + (1 - c->gamma_) * digamma_host(c->gamma_)) + sumlogdelta; // :469
+    *lb = Lb;
     return VBMF_OK;
 }
 
