@@ -35,6 +35,7 @@ CONFIGS = {
     "cfg3": (100000, 10000, 64, "bf16"),
     "cfg2": (10000, 1000, 32, "f32"),
     "cfg4": (1000000, 10000, 128, "bf16"),
+    "cfg5": (100000, 10000, 256, "bf16"),      # vbmf_sparse.jl ARD-sparse (diagonal branch)
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
@@ -124,8 +125,10 @@ def main():
     L_loc = base + (1 if rank < rem else 0)
     row0 = rank * base + min(rank, rem)
 
+    sparse = (a.config == "cfg5")
     ctx = capi.Context(L_loc, M, H, y_dtype=y_dtype, factor_dtype=f_dtype, device=local_rank, nranks=world,
-                       rank=rank, L_global=L, row_offset=row0, pass1_splits=a.splits)
+                       rank=rank, L_global=L, row_offset=row0, pass1_splits=a.splits,
+                       variant=capi.VBMF_VARIANT_SPARSE_DIAG if sparse else capi.VBMF_VARIANT_BASIC)
     if world > 1:
         uid = [capi.Context.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
@@ -136,7 +139,14 @@ def main():
     A0 = rng.standard_normal((M, H))
     B0 = rng.standard_normal((L, H))[row0:row0 + L_loc]
     z = np.zeros((H, H))
-    ctx.set_state(A0, B0, z, z, 0.1 * np.ones(H), 0.1 * np.ones(H), 0.1)
+    if sparse:      # vbmf_sparse_init defaults (src/vbmf_sparse.jl:101-104) with ca = cb = sigma = 0.1 (examples/toy_data.jl:53)
+        hyper = dict(alpha0=1e-10, beta0=1e-10, gamma0=1e-10, delta0=1e-10, eta0=1e-10, zeta0=1e-10)
+        ctx.sparse_set_state(A0.reshape(M * H), np.ones(M * H), 0.1 * np.ones(M * H), 1e-10 * np.ones(M * H), B0, z,
+                             0.1 * np.ones(H), 1e-10 * np.ones(H), 0.1, 1e-10, hyper)
+        run = lambda k: ctx.sparse_run(k, eps=0.0, est_cb=True)
+    else:
+        ctx.set_state(A0, B0, z, z, 0.1 * np.ones(H), 0.1 * np.ones(H), 0.1)
+        run = lambda k: ctx.run(k, eps=0.0, est_covs=True, est_var=True)
     del A0, B0
 
     def barrier():
@@ -146,11 +156,11 @@ def main():
         ctx.sync()
 
     if a.warmup > 0:
-        ctx.run(a.warmup, eps=0.0, est_covs=True, est_var=True)
+        run(a.warmup)
     ctx.profile_enable(True)
     barrier()
     t0 = time.perf_counter()
-    it, d, _ = ctx.run(a.steps, eps=0.0, est_covs=True, est_var=True)
+    it, d, _ = run(a.steps)
     barrier()
     t1 = time.perf_counter()
     prof = ctx.profile_read()
@@ -163,7 +173,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    s = ctx.get_state(want_B=False)
+    s = {"sigma2": ctx.sparse_get_state(want_B=False)["sigmaHat"]} if sparse else ctx.get_state(want_B=False)
     bytes1, bytes2 = ctx.pass_bytes(1), ctx.pass_bytes(2)
     n = prof["pass1_n"] + prof["pass2_n"]
     avg_ms = (prof["pass1_ms"] + prof["pass2_ms"]) / max(n, 1)
@@ -208,7 +218,10 @@ def main():
         },
         "final": {"sigma2": s["sigma2"], "d": d},
     }
-    if rank == 0 and not a.no_cpu_baseline and world == 1:
+    if sparse:
+        out["metric"] = "VB iterations/sec (vbmf_sparse!, diagonal branch)"
+        out["config"]["workload"] = out["config"]["workload"].replace("vbmf! sweep, est_covs=est_var=true", "vbmf_sparse! sweep (full_cov=false, diag_var=false, est_cb=true)")
+    if rank == 0 and not a.no_cpu_baseline and world == 1 and not sparse:
         out["cpu_baseline"] = cpu_baseline(ctx, L, M, H, a.cpu_rows, a.cpu_sweeps, 20170102)
     elif rank == 0:
         out["cpu_baseline"] = None

@@ -329,3 +329,18 @@ def test_single_rank_communicator_runs_the_collective_path(pkg):
     for k in ("AHat", "BHat", "SigmaA", "SigmaB", "CA_diag", "CB_diag"):
         assert np.array_equal(s0[k], s1[k]), k
     assert s0["sigma2"] == s1["sigma2"] and abs(e0 - e1) <= 1e-9 * abs(e0)
+
+
+def test_rank_above_128_slow_path(pkg):
+    """H > 128 (the sparse config-5 rank, 256): stand-alone control kernels (1024-thread Gauss-Jordan, power-iteration
+    lambda_max), un-fused Gram, NH = 8 streaming tiles.  Functional parity only; this path is not tuned."""
+    L, M, H = 900, 640, 200
+    Y, po = _problem(L, M, H, 333)
+    ydt, fdt, tol = _mode_opts(pkg, "bf16x2")
+    Ys = _stored(pkg, Y, H, ydt, fdt)
+    pkg.set_defaults(y_dtype=ydt, factor_dtype=fdt)
+    pg = to_pkg_params(pkg, po)
+    pkg.vbmf_(Ys, pg, 2, eps=0.0, est_covs=True, est_var=True)
+    _, n, d = O.vbmf_(Ys, po, 2, eps=0.0, est_covs=True, est_var=True)
+    compare("bf16x2 900x640 H200 run2", pg, po, {k: 6 * v for k, v in tol.items()})
+    assert abs(pg._last_run[1] - d) <= 2e-2 * d

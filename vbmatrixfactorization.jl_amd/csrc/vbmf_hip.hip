@@ -388,7 +388,7 @@ static int launch_eig(vbmf_ctx* c, int do_d, int do_b) {
     else if (H <= 128) launch_eig_t<8>(c, do_d, do_b, s);
     else {
         const int spectral = (c->o.reference_compat & VBMF_COMPAT_SPECTRAL_DELTA) ? 1 : 0;
-        hipLaunchKernelGGL(eig_jacobi_kernel, dim3(2), dim3(1024), 0, s, c->st, c->lay, H, spectral, do_d, do_b, c->ints, 0);
+        hipLaunchKernelGGL(eig_power_kernel, dim3(2), dim3(1024), 0, s, c->st, c->lay, H, spectral, do_d, do_b, c->ints);
     }
     HIPCHK(c, hipGetLastError());
     return VBMF_OK;
