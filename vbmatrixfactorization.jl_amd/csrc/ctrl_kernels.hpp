@@ -218,14 +218,13 @@ constexpr int EIG_NSQ = 14;
 // which = 0: GD -> S_LAMD, 1: GB -> S_LAMB_NEW.  256 threads, 2*NP*(NP+4) floats of LDS (NP = 16R).
 template <int R>
 __device__ __forceinline__ void eig_dev(double* __restrict__ st, StateLayout lay, int H, int spectral, int which,
-                                        const int* __restrict__ ints, float* ldsf) {
+                                        const int* __restrict__ ints, float* ldsf, int slot) {
     __shared__ double red[16];
     __shared__ int s_arg;
     if (load_stop(ints)) return;
     const int Hp = lay.Hp;
     const double* G = st + (which == 0 ? lay.GD() : lay.GB());
     double* scal = st + lay.scal();
-    const int slot = which == 0 ? S_LAMD : S_LAMB_NEW;
     double tr = 0.0;
     for (int i = threadIdx.x; i < H; i += blockDim.x) tr += G[(long long)i * Hp + i];
     tr = block_sum(tr, red);
@@ -323,7 +322,7 @@ __global__ __launch_bounds__(256) void eig_kernel(double* __restrict__ st, State
     extern __shared__ __attribute__((aligned(16))) float lds_eig[];
     const int which = blockIdx.x;           // 0: GD, 1: GB
     if ((which == 0 && !do_d) || (which == 1 && !do_b)) return;
-    eig_dev<R>(st, lay, H, spectral, which, ints, lds_eig);
+    eig_dev<R>(st, lay, H, spectral, which, ints, lds_eig, which == 0 ? S_LAMD : S_LAMB_NEW);
 }
 
 // Fallback for H > 128 (the squaring kernel's two LDS tiles do not fit): 1024 threads, fp64 power iteration
@@ -379,7 +378,8 @@ __global__ __launch_bounds__(1024) void eig_power_kernel(double* __restrict__ st
 }
 
 // flags: bit0 est_covs->CA, bit1 est_covs->CB, bit2 est_var, bit3 compute d + loop bookkeeping,
-//        bit4 tr(Y'BA') from the Gram identity tr(KB o GB) (else from scal[S_TRDOT])
+//        bit4 tr(Y'BA') from the Gram identity tr(KB o GB) (else from scal[S_TRDOT]),
+//        bit5 S_LAMB_PREV already holds lambda_max of the old B'B (no rotation from S_LAMB_NEW)
 __device__ __forceinline__ void ctrl_end_dev(double* __restrict__ st, StateLayout lay, int H, double Lg, double M,
                                              int flags, double eps, double* __restrict__ trace,
                                              int* __restrict__ ints) {
@@ -433,7 +433,7 @@ __device__ __forceinline__ void ctrl_end_dev(double* __restrict__ st, StateLayou
         if (flags & 8) {
             const double d = sqrt(scal[S_LAMD] / scal[S_LAMB_PREV]);
             scal[S_D] = d;
-            scal[S_LAMB_PREV] = scal[S_LAMB_NEW];
+            if (!(flags & 32)) scal[S_LAMB_PREV] = scal[S_LAMB_NEW];   // (32: lambda_max of the old B is written there directly)
             const int it = ints[I_ITERS];
             if (trace) { trace[4 * it + 0] = d; trace[4 * it + 1] = sigma2; trace[4 * it + 2] = F; trace[4 * it + 3] = resid; }
             ints[I_ITERS] = it + 1;
@@ -460,20 +460,27 @@ struct CtrlArgs {
     float* S32;            // SigmaA/sigma2 (pass 1) or SigmaB/sigma2 (pass 2) table for the post kernel
     double Lg, M, eps;
     int H, spectral, end_flags;
-    int mode;              // bit0: lambda_max(GD), lambda_max(GB) + ctrl_end of the PREVIOUS sweep;
-                           // bit1: SigmaA; bit2: SigmaB; 0: no control workgroup in this launch
+    int mode;              // CTRL_* bits; 0: no control workgroup in this launch
 };
-enum : int { CTRL_PREV_END = 1, CTRL_COV_A = 2, CTRL_COV_B = 4 };
+// Schedule inside vbmf_run (sweep j; B_{j-1} is the factor the sweep starts from):
+//   pass 1 of sweep j : [lambda_max(dB'dB) of sweep j-1, ctrl_end of sweep j-1]  then  SigmaA of sweep j
+//   pass 2 of sweep j : SigmaB of sweep j  and  lambda_max(B_{j-1}'B_{j-1})  (the denominator of d_j; the
+//                       Gram of B_{j-1} is still in place: post(B) of sweep j runs after this launch)
+// so each pass carries a chain of similar length (~75 / ~65 us at H = 64).
+enum : int { CTRL_PREV_END = 1, CTRL_COV_A = 2, CTRL_COV_B = 4, CTRL_EIG_BOLD = 8 };
 
 template <int R>
 __device__ __forceinline__ void ctrl_chain(const CtrlArgs& a, void* lds) {
     if (a.mode & CTRL_PREV_END) {
-        eig_dev<R>(a.st, a.lay, a.H, a.spectral, 0, a.ints, reinterpret_cast<float*>(lds));
-        eig_dev<R>(a.st, a.lay, a.H, a.spectral, 1, a.ints, reinterpret_cast<float*>(lds));
-        ctrl_end_dev(a.st, a.lay, a.H, a.Lg, a.M, a.end_flags, a.eps, a.trace, a.ints);
+        eig_dev<R>(a.st, a.lay, a.H, a.spectral, 0, a.ints, reinterpret_cast<float*>(lds), S_LAMD);
+        ctrl_end_dev(a.st, a.lay, a.H, a.Lg, a.M, a.end_flags | 32, a.eps, a.trace, a.ints);
     }
     if (a.mode & CTRL_COV_A) ctrl_cov_dev<R, 16>(a.st, a.lay, a.H, 0, a.Lg, a.S32, a.ints, reinterpret_cast<double*>(lds));
     if (a.mode & CTRL_COV_B) ctrl_cov_dev<R, 16>(a.st, a.lay, a.H, 1, a.M, a.S32, a.ints, reinterpret_cast<double*>(lds));
+    if (a.mode & CTRL_EIG_BOLD) {
+        __syncthreads();
+        eig_dev<R>(a.st, a.lay, a.H, a.spectral, 1, a.ints, reinterpret_cast<float*>(lds), S_LAMB_PREV);
+    }
 }
 
 __global__ void copy_scalar_kernel(double* st, StateLayout lay, int dst, int src) {

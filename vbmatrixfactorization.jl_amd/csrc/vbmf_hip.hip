@@ -179,7 +179,10 @@ static void plan_pass(Dims& d, int64_t X, int64_t K, int kstep, int NH, int Hp, 
         for (int cand = 1; cand <= ns_max; ++cand) {
             const int blocks = bps * cand;
             const int rounds = (blocks + NUM_CU - 1) / NUM_CU;
-            const double t = std::max(rounds * (total / blocks) / R_CU, total / R_HBM) + cand * out_bytes * 2.0 / R_HBM;
+            // split-K partials: written at HBM rate, re-read by a latency-bound consumer at ~1.5 TB/s
+            // (measured: 5 slabs of 25.6 MB cost the post kernel +150 us)
+            const double slab = cand > 1 ? cand * out_bytes * (1.0 / R_HBM + 1.0 / 1.5e12) : 0.0;
+            const double t = std::max(rounds * (total / blocks) / R_CU, total / R_HBM) + slab;
             if (t < best * 0.999) { best = t; ns = cand; }
         }
     }
@@ -464,7 +467,7 @@ static int do_update_A(vbmf_ctx* c) {
 static int do_update_B(vbmf_ctx* c) {
     TRY(ensure_gram_A(c));
     if (fused_ctrl(c)) {
-        TRY(launch_stream(c, 1, CTRL_COV_B));
+        TRY(launch_stream(c, 1, CTRL_COV_B | CTRL_EIG_BOLD));
     } else {
         TRY(launch_ctrl_cov(c, 1));
         TRY(launch_stream(c, 1));
@@ -942,11 +945,14 @@ int vbmf_run(vbmf_ctx* c, int64_t niter, double eps, int est_covs, int est_var, 
     }
     int init[4] = {0, 0, 0, (int)niter};
     HIPCHK(c, hipMemcpyAsync(c->ints, init, sizeof init, hipMemcpyHostToDevice, c->stream));
-    // ||B_old||_2 of the first comparison (src/vbmf.jl:187-188: old = params.BHat)
+    // ||B_old||_2 of the first comparison (src/vbmf.jl:187-188: old = params.BHat): in the fused schedule
+    // every sweep's pass-2 launch computes it; otherwise once here, then rotated by ctrl_end
     int rc = ensure_gram_B(c);
-    if (rc == VBMF_OK) rc = launch_eig(c, 0, 1);
-    if (rc == VBMF_OK) {
-        hipLaunchKernelGGL(copy_scalar_kernel, dim3(1), dim3(1), 0, c->stream, c->st, c->lay, (int)S_LAMB_PREV, (int)S_LAMB_NEW);
+    const bool fused_run = (c->NH <= 4);
+    if (rc == VBMF_OK && !fused_run) {
+        rc = launch_eig(c, 0, 1);
+        if (rc == VBMF_OK)
+            hipLaunchKernelGGL(copy_scalar_kernel, dim3(1), dim3(1), 0, c->stream, c->st, c->lay, (int)S_LAMB_PREV, (int)S_LAMB_NEW);
     }
     const int flags = (est_covs ? 3 : 0) | (est_var ? 4 : 0) | 8 | 16;
     const int bstart = c->bcur;
@@ -966,6 +972,9 @@ int vbmf_run(vbmf_ctx* c, int64_t niter, double eps, int est_covs, int est_var, 
         if (rc == VBMF_OK) {
             if (fused_ctrl(c) && !checkpoint) {
                 c->tail_pending = true;      // rides in the next sweep's pass-1 launch
+            } else if (fused_ctrl(c)) {
+                rc = launch_eig(c, 1, 0);
+                if (rc == VBMF_OK) rc = launch_ctrl_end(c, flags | 32, eps, trace_dev);
             } else {
                 rc = launch_eig(c, 1, 1);
                 if (rc == VBMF_OK) rc = launch_ctrl_end(c, flags, eps, trace_dev);
