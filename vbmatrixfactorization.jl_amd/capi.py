@@ -23,7 +23,7 @@ SYMBOLS = [
     "vbmf_default_opts", "vbmf_create", "vbmf_destroy", "vbmf_last_error", "vbmf_set_Y", "vbmf_set_Y_synthetic",
     "vbmf_get_Y", "vbmf_get_trYY", "vbmf_set_state", "vbmf_get_state", "vbmf_step", "vbmf_run", "vbmf_get_YHat",
     "vbmf_elbo", "vbmf_comm_unique_id", "vbmf_comm_init", "vbmf_profile_enable", "vbmf_profile_read",
-    "vbmf_pass_bytes", "vbmf_device_sync", "vbmf_debug_peek",
+    "vbmf_pass_bytes", "vbmf_device_sync", "vbmf_debug_peek", "vbmf_debug_time_pass",
     "vbmf_sparse_set_state", "vbmf_sparse_get_state", "vbmf_sparse_step", "vbmf_sparse_run", "vbmf_sparse_lower_bound",
 ]
 SSTEP_A, SSTEP_B, SSTEP_CA, SSTEP_CB, SSTEP_SIGMA = 1, 2, 4, 8, 16
@@ -95,6 +95,7 @@ def lib():
     L.vbmf_pass_bytes.argtypes = [vp, i32, dp]
     L.vbmf_device_sync.argtypes = [vp]
     L.vbmf_debug_peek.argtypes = [vp, i32, C.POINTER(C.c_uint32), i64, i64]
+    L.vbmf_debug_time_pass.argtypes = [vp, i32, i32, dp]
     L.vbmf_sparse_set_state.argtypes = [vp, dp, dp, dp, dp, dp, i64, dp, dp, dp, C.c_double, C.c_double,
                                         C.POINTER(VbmfSparseHyper), C.POINTER(i64), i64, i64]
     L.vbmf_sparse_get_state.argtypes = [vp, dp, dp, dp, dp, dp, dp, i64, dp, dp, dp, dp, dp]
@@ -300,6 +301,11 @@ class Context:
         v = self.peek(PEEK_DIMS, 16, dtype=np.int32)
         keys = ["Hp", "NH", "mode", "XT1", "KS1", "nsplit1", "sps1", "XT2", "KS2", "nsplit2", "sps2", "kstep", "npart"]
         return dict(zip(keys, (int(x) for x in v)))
+
+    def time_pass(self, p, iters=10):
+        v = C.c_double()
+        self._chk(self._lib.vbmf_debug_time_pass(self._h, p, iters, C.byref(v)))
+        return v.value
 
     def sync(self):
         self._chk(self._lib.vbmf_device_sync(self._h))

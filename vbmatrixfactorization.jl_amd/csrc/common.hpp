@@ -57,16 +57,16 @@ __device__ __forceinline__ float bf2f(unsigned short u) {
     return __builtin_bit_cast(float, ((unsigned)u) << 16);
 }
 
-// padding quanta shared by every tiled buffer: k-step counts are multiples of PIPE_D (the streaming
-// kernel's ring depths divide it) and x-tile counts are multiples of XT_PAD (its per-wave tile count does)
+// PIPE_D: upper bound of the streaming kernel's ring depths (its run-ahead over-reads at most that many
+// tiles: every tiled buffer carries PIPE_D tiles of slack).  The actual padding quanta are per rank class
+// (host planner): x tiles to the per-wave tile count NXW = 8/NH, k-steps to the Y ring depth.
 constexpr int PIPE_D = 12;
-constexpr int XT_PAD = 8;
 
 struct Dims {               // one streaming pass: Out[h][x] = sum_k F[k][h] * Y[k][x]
-    int XT;                 // 32-wide x tiles, multiple of XT_PAD
-    int KS;                 // k-steps, multiple of nsplit*PIPE_D
+    int XT;                 // 32-wide x tiles, multiple of the per-wave tile count
+    int KS;                 // k-steps, multiple of nsplit * (Y ring depth)
     int nsplit;             // split-K factor
-    int steps_per_split;    // KS / nsplit, multiple of PIPE_D
+    int steps_per_split;    // KS / nsplit, multiple of the Y ring depth
 };
 
 }  // namespace vbmf

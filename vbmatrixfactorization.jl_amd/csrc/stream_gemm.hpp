@@ -52,7 +52,6 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const uint4* __restric
     constexpr int NPART = ModeTraits<MODE>::NPART;
     constexpr int NF = NPART * NH;
     static_assert(PIPE_D % DY == 0 && DY % DF == 0, "ring depths must divide the padding quantum");
-    static_assert(XT_PAD % NXW_ == 0, "tiles per wave must divide the x padding quantum");
     int bid = blockIdx.x;
     if (ctrl.mode != 0) {                                 // launch carries a control workgroup (dispatched first)
         if (bid == 0) {

@@ -155,6 +155,7 @@ template <> struct StreamCfg<4> { static constexpr int NXWc = 2; static constexp
 template <> struct StreamCfg<8> { static constexpr int NXWc = 1; static constexpr int DYc = 4; static constexpr int DFc = 1; static constexpr int Rc = 0; };
 
 static int nxw_of(int NH) { return 8 / NH; }
+static int dy_of(int NH) { return NH == 1 ? 3 : (NH == 8 ? 4 : 6); }    // = StreamCfg<NH>::DYc
 // one CU is left to the control workgroup that rides in each pass launch
 constexpr int NUM_CU = 255;
 
@@ -164,8 +165,11 @@ constexpr int NUM_CU = 255;
 // with rounds = ceil(blocks / 256).  Pick the split factor minimising that (measured at 100k x 10k:
 // 240 blocks 0.35 ms, 260 blocks 0.61 ms, 160 blocks 0.44 ms -- the model's ordering).
 static void plan_pass(Dims& d, int64_t X, int64_t K, int kstep, int NH, int Hp, double ybytes, int want_splits) {
-    d.XT = (int)rup(cdiv(X, 32), XT_PAD);
-    const int64_t ks_min = rup(cdiv(rup(K, 32 * XT_PAD), kstep), PIPE_D);   // K padded like the other pass's x tiles
+    // padding quanta: x tiles to the per-wave tile count, k-steps to the Y ring depth (zero tiles are streamed
+    // like real ones, so padding is pure waste: 3.7 % of pass 2 at 100k x 10k with the old 8-tile / 12-step quanta)
+    const int xq = nxw_of(NH), kq = dy_of(NH);
+    d.XT = (int)rup(cdiv(X, 32), xq);
+    const int64_t ks_min = rup(cdiv(rup(K, 32 * xq), kstep), kq);   // K padded like the other pass's x tiles
     const int XG = d.XT / nxw_of(NH);
     const int bps = (XG + 3) / 4;
     int ns = want_splits;
@@ -173,7 +177,7 @@ static void plan_pass(Dims& d, int64_t X, int64_t K, int kstep, int NH, int Hp, 
         const double R_CU = 24e9, R_HBM = 5.4e12;   // measured in the sweep pipeline (200 vs 240 blocks: 0.434 vs 0.390 ms)
         const double total = (double)d.XT * 32.0 * (double)ks_min * kstep * ybytes;
         const double out_bytes = (double)Hp * d.XT * 32.0 * 4.0;
-        const int ns_max = (int)std::max<int64_t>(1, std::min<int64_t>(64, ks_min / (2 * PIPE_D)));
+        const int ns_max = (int)std::max<int64_t>(1, std::min<int64_t>(64, ks_min / (2 * kq)));
         double best = 1e300;
         ns = 1;
         for (int cand = 1; cand <= ns_max; ++cand) {
@@ -186,9 +190,9 @@ static void plan_pass(Dims& d, int64_t X, int64_t K, int kstep, int NH, int Hp, 
             if (t < best * 0.999) { best = t; ns = cand; }
         }
     }
-    ns = (int)std::max<int64_t>(1, std::min<int64_t>(ns, std::max<int64_t>(1, ks_min / PIPE_D)));
+    ns = (int)std::max<int64_t>(1, std::min<int64_t>(ns, std::max<int64_t>(1, ks_min / kq)));
     d.nsplit = ns;
-    d.steps_per_split = (int)rup(cdiv(ks_min, d.nsplit), PIPE_D);
+    d.steps_per_split = (int)rup(cdiv(ks_min, d.nsplit), kq);
     d.KS = d.steps_per_split * d.nsplit;
 }
 
@@ -1134,6 +1138,31 @@ int vbmf_debug_peek(vbmf_ctx* c, int what, uint32_t* out, int64_t nwords, int64_
     if ((size_t)(word_offset + nwords) > words) FAIL(c, VBMF_ERR_INVALID, "vbmf_debug_peek: range exceeds buffer (%zu words)", words);
     HIPCHK(c, hipMemcpy(out, (const uint32_t*)base + word_offset, (size_t)nwords * 4, hipMemcpyDeviceToHost));
     return VBMF_OK;
+}
+
+int vbmf_debug_time_pass(vbmf_ctx* c, int pass, int iters, double* ms) {
+    if (!c || !ms || (pass != 1 && pass != 2) || iters < 1) return VBMF_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->o.device));
+    TRY(ensure_ready(c));
+    hipEvent_t a, b;
+    HIPCHK(c, hipEventCreate(&a));
+    HIPCHK(c, hipEventCreate(&b));
+    const bool prof = c->prof;
+    c->prof = false;
+    int rc = launch_stream(c, pass - 1);
+    if (rc == VBMF_OK) rc = launch_stream(c, pass - 1);
+    hipEventRecord(a, c->stream);
+    for (int i = 0; i < iters && rc == VBMF_OK; ++i) rc = launch_stream(c, pass - 1);
+    hipEventRecord(b, c->stream);
+    hipEventSynchronize(b);
+    float t = 0.f;
+    hipEventElapsedTime(&t, a, b);
+    hipEventDestroy(a);
+    hipEventDestroy(b);
+    c->prof = prof;
+    c->P_valid = false;
+    *ms = t / iters;
+    return rc;
 }
 
 int vbmf_device_sync(vbmf_ctx* c) {
