@@ -6,6 +6,7 @@
 #include <vector>
 #include <string>
 #include "common.hpp"
+#include "stream_gemm.hpp"
 using namespace vbmf;
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
@@ -226,6 +227,47 @@ int main(int argc, char** argv) {
     const int H = 64, NH = 2;
     // pass 1: X = M = 10000, K = L = 100000;  pass 2: X = L, K = M
     Prob probs[2] = {{10000, 100000, H, "pass1 (x=M=10k, k=L=100k)"}, {100000, 10000, H, "pass2 (x=L=100k, k=M=10k)"}};
+    {
+        // per-CU ceiling probe at the pass-2 shape: 196 blocks x 4 waves, NXW = 4
+        const long long X = 100000, K = 10000;
+        const int XT = 3128, KS = 636, XG = XT / 4, bps = (XG + 3) / 4;
+        const double ybytes = (double)XT * 32 * KS * 16 * 2.0;
+        uint4* Y; float* O; uint4* F;
+        const size_t nY = (size_t)XT * KS * 64 + 4096;
+        CK(hipMalloc(&Y, nY * 16)); CK(hipMalloc(&O, (size_t)64 * XT * 32 * 4 + 4096)); CK(hipMalloc(&F, (size_t)(KS + 16) * 4 * 64 * 16));
+        fill_random(Y, std::min<size_t>(nY, (size_t)1 << 24));
+        for (size_t off = (size_t)1 << 24; off < nY; off += (size_t)1 << 24)
+            CK(hipMemcpy(Y + off, Y, std::min<size_t>((size_t)1 << 24, nY - off) * 16, hipMemcpyDeviceToDevice));
+        fill_random(F, (size_t)(KS + 16) * 4 * 64);
+        printf("== per-CU ceiling probe (pass-2 shape, grid = %d blocks of 4 waves)\n", bps);
+        double ms;
+        ms = time_ms([&] { hipLaunchKernelGGL((k_read<4, 6, 2>), dim3(bps), dim3(256), 0, 0, Y, O, XG, KS, KS, 1); }, 10);
+        printf("  pure read NXW4 D6  : %.3f ms %.0f GB/s\n", ms, ybytes / ms / 1e6);
+        ms = time_ms([&] { hipLaunchKernelGGL((k_read<4, 12, 2>), dim3(bps), dim3(256), 0, 0, Y, O, XG, KS, KS, 1); }, 10);
+        printf("  pure read NXW4 D12 : %.3f ms %.0f GB/s\n", ms, ybytes / ms / 1e6);
+        const long long ld = (long long)XT * 32;
+        ms = time_ms([&] { hipLaunchKernelGGL((k_stream2<2, 4, 6, 2, 4, 1, 0>), dim3(bps), dim3(256), 0, 0, Y, F, O, XG, KS, KS, 1, ld); }, 10);
+        printf("  full kernel DY6 DF2: %.3f ms %.0f GB/s\n", ms, ybytes / ms / 1e6);
+        ms = time_ms([&] { hipLaunchKernelGGL((k_stream2<2, 4, 12, 3, 4, 1, 0>), dim3(bps), dim3(256), 0, 0, Y, F, O, XG, KS, KS, 1, ld); }, 10);
+        printf("  full kernel DY12 DF3: %.3f ms %.0f GB/s\n", ms, ybytes / ms / 1e6);
+        ms = time_ms([&] { hipLaunchKernelGGL((k_stream<2, 2, 4, 3, 2, 2, 4, 1>), dim3(bps), dim3(256), 0, 0, Y, F, O, XG, KS, KS, 1, ld); }, 10);
+        printf("  kernel, no F loads : %.3f ms %.0f GB/s\n", ms, ybytes / ms / 1e6);
+        {
+            CtrlArgs ca{}; ca.mode = 0;
+            int* stopflag; CK(hipMalloc(&stopflag, 64)); CK(hipMemset(stopflag, 0, 64));
+            ms = time_ms([&] { hipLaunchKernelGGL((stream_gemm_kernel<2, 2, 4, 6, 2, 4>), dim3(bps), dim3(256), 0, 0, Y, F, O, XG, KS, KS, 1, ld, stopflag, ca); }, 10);
+            printf("  PRODUCT kernel (ctrl off, stop ptr): %.3f ms %.0f GB/s\n", ms, ybytes / ms / 1e6);
+            ms = time_ms([&] { hipLaunchKernelGGL((stream_gemm_kernel<2, 2, 4, 6, 2, 4>), dim3(bps), dim3(256), 0, 0, Y, F, O, XG, KS, KS, 1, ld, (const int*)nullptr, ca); }, 10);
+            printf("  PRODUCT kernel (ctrl off, no stop) : %.3f ms %.0f GB/s\n", ms, ybytes / ms / 1e6);
+            ms = time_ms([&] { hipLaunchKernelGGL((stream_gemm_kernel<2, 2, 4, 6, 2, 0>), dim3(bps), dim3(256), 0, 0, Y, F, O, XG, KS, KS, 1, ld, (const int*)nullptr, ca); }, 10);
+            printf("  PRODUCT kernel RCTRL=0 instantiation: %.3f ms %.0f GB/s\n", ms, ybytes / ms / 1e6);
+            ms = time_ms([&] { hipLaunchKernelGGL((k_stream2<2, 4, 6, 2, 4, 1, 0>), dim3(bps), dim3(256), 0, 0, Y, F, O, XG, KS, KS, 1, ld); }, 10);
+            printf("  harness kernel again               : %.3f ms %.0f GB/s\n", ms, ybytes / ms / 1e6);
+        }
+        // 8 waves per CU via 2 blocks/CU is impossible at >256 regs; try 512-thread blocks of NXW2 (occupancy 2)
+        CK(hipFree(Y)); CK(hipFree(O)); CK(hipFree(F));
+        return 0;
+    }
     for (int pi = 0; pi < 2; ++pi) {
         const Prob& p = probs[pi];
         const int XT = (int)((p.X + 255) / 256 * 8);

@@ -135,16 +135,18 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const uint4* __restric
             }
             // ... and refill both at once (Y: step +DY, factor: step +DF).  MFMAs read their operands at
             // issue and a wave issues in order, so the refill may target the registers just consumed.
-            // The lead-in's factor steps are clamped to step 0 (finite data times the zero Y ring); the
-            // run-ahead past the split lands in the next split's tiles or in the buffers' PIPE_D tiles of
-            // slack and is never consumed.  Nothing here relies on the descriptor's bounds check (the SGPR
-            // offset is not part of it).
+            // The lead-in's factor steps are negative: they read the previous split's tiles or the PIPE_D
+            // zero tiles in FRONT of the factor buffer (finite data times the zero Y ring).  The run-ahead
+            // past the split lands in the next split's tiles or in the trailing slack and is never
+            // consumed.  Nothing relies on the descriptor's bounds check (the SGPR offset is not part of
+            // it).  (Clamping the lead-in step with max(.,0) instead cost 12 %: hipcc peels the lead-in
+            // iteration and its waits serialise every wave's pipeline fill.)
 #pragma unroll
             for (int i = 0; i < NXW_; ++i)
                 yb[d][i] = __builtin_amdgcn_raw_buffer_load_b128(yr[i], voff, (s + DY + d) * 1024, Y_AUX);
 #pragma unroll
             for (int j = 0; j < NF; ++j)
-                fb[fd][j] = __builtin_amdgcn_raw_buffer_load_b128(fr, voff, (max(s + d + DF, 0) * NF + j) * 1024, 0);
+                fb[fd][j] = __builtin_amdgcn_raw_buffer_load_b128(fr, voff, ((s + d + DF) * NF + j) * 1024, 0);
             // pin that order in the emitted stream (otherwise hipcc sinks every refill to the loop bottom
             // and drains vmcnt(0) each iteration)
             constexpr int NMFMA = NXW_ * NF * (MODE == MODE_F32 ? 4 : 1);

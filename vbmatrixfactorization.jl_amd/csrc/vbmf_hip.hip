@@ -50,7 +50,8 @@ struct vbmf_ctx {
     int Hp = 0, NH = 0, mode = 0, kstep = 16, npart = 1;
     Dims d1{}, d2{};                 // pass 1: x=m,k=l ; pass 2: x=l,k=m
     int64_t Mp = 0, Lp = 0;
-    uint4 *Y1 = nullptr, *Y2 = nullptr, *FA = nullptr, *FB = nullptr;
+    uint4 *Y1 = nullptr, *Y2 = nullptr, *FA = nullptr, *FB = nullptr;   // FA/FB point PAST PIPE_D leading zero k-steps
+    uint4 *FA_alloc = nullptr, *FB_alloc = nullptr;
     size_t nY1 = 0, nY2 = 0, nFA = 0, nFB = 0;
     float *P = nullptr, *Q = nullptr, *Pred = nullptr;
     float *A32 = nullptr, *B32[2] = {nullptr, nullptr};
@@ -558,7 +559,7 @@ int vbmf_destroy(vbmf_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     prof_harvest(c);
     if (c->comm) ncclCommDestroy(c->comm);
-    void* bufs[] = {c->Y1, c->Y2, c->FA, c->FB, c->P, c->Q, c->Pred, c->A32, c->B32[0], c->B32[1], c->SA32,
+    void* bufs[] = {c->Y1, c->Y2, c->FA_alloc, c->FB_alloc, c->P, c->Q, c->Pred, c->A32, c->B32[0], c->B32[1], c->SA32,
                     c->SB32, c->gslab, c->st, c->gtmp, c->ypart, c->ints, c->mask, c->dS32, c->CA32, c->beta32, c->vtab};
     for (void* b : bufs) if (b) hipFree(b);
     if (c->ints_host) hipHostFree(c->ints_host);
@@ -634,12 +635,16 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
     const size_t slack = (size_t)PIPE_D * 64;
     c->nY1 = (size_t)c->d1.XT * c->d1.KS * 64 + slack * 2;
     c->nY2 = (size_t)c->d2.XT * c->d2.KS * 64 + slack * 2;
+    // factor tiles: PIPE_D zero k-steps in front (the streaming kernel's lead-in reads steps -DF..-1) and behind
+    const size_t flead = (size_t)PIPE_D * c->npart * c->NH * 64;
     c->nFB = ((size_t)c->d1.KS + PIPE_D) * c->npart * c->NH * 64;
     c->nFA = ((size_t)c->d2.KS + PIPE_D) * c->npart * c->NH * 64;
     ALLOC(c->Y1, c->nY1 * 16);
     ALLOC(c->Y2, c->nY2 * 16);
-    ALLOC(c->FB, c->nFB * 16);
-    ALLOC(c->FA, c->nFA * 16);
+    ALLOC(c->FB_alloc, (c->nFB + flead) * 16);
+    ALLOC(c->FA_alloc, (c->nFA + flead) * 16);
+    c->FB = c->FB_alloc + flead;
+    c->FA = c->FA_alloc + flead;
     ALLOC(c->P, (size_t)c->d1.nsplit * c->Hp * c->Mp * 4);
     ALLOC(c->Q, (size_t)c->d2.nsplit * c->Hp * c->Lp * 4);
     ALLOC(c->Pred, (size_t)c->Hp * c->Mp * 4);
