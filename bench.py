@@ -183,7 +183,8 @@ def main():
     # (scripts/pmc_traffic.sh); report the committed measurement when it is for exactly this workload
     traffic = None
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_c_pmc_stream_kernel_cfg3.json")))
+        import glob
+        pm = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_stream_kernel_cfg3.json")))[-1]))
         k = pm["config"]
         if (k["L"], k["M"], k["H"], k["y_dtype"], k["n_gpus"]) == (L, M, H, ydt, world) and a.factor in ("auto", "bf16x2"):
             traffic = pm["traffic_bytes_per_launch"]
