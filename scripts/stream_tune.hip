@@ -255,11 +255,11 @@ int main(int argc, char** argv) {
         {
             CtrlArgs ca{}; ca.mode = 0;
             int* stopflag; CK(hipMalloc(&stopflag, 64)); CK(hipMemset(stopflag, 0, 64));
-            ms = time_ms([&] { hipLaunchKernelGGL((stream_gemm_kernel<2, 2, 4, 6, 2, 4>), dim3(bps), dim3(256), 0, 0, Y, F, O, XG, KS, KS, 1, ld, stopflag, ca); }, 10);
+            ms = time_ms([&] { hipLaunchKernelGGL((stream_gemm_kernel<2, 2, 4, 6, 2, 4>), dim3(bps), dim3(256), 0, 0, Y, F, O, XG, KS, KS, 1, ld, stopflag, ca, 0); }, 10);
             printf("  PRODUCT kernel (ctrl off, stop ptr): %.3f ms %.0f GB/s\n", ms, ybytes / ms / 1e6);
-            ms = time_ms([&] { hipLaunchKernelGGL((stream_gemm_kernel<2, 2, 4, 6, 2, 4>), dim3(bps), dim3(256), 0, 0, Y, F, O, XG, KS, KS, 1, ld, (const int*)nullptr, ca); }, 10);
+            ms = time_ms([&] { hipLaunchKernelGGL((stream_gemm_kernel<2, 2, 4, 6, 2, 4>), dim3(bps), dim3(256), 0, 0, Y, F, O, XG, KS, KS, 1, ld, (const int*)nullptr, ca, 0); }, 10);
             printf("  PRODUCT kernel (ctrl off, no stop) : %.3f ms %.0f GB/s\n", ms, ybytes / ms / 1e6);
-            ms = time_ms([&] { hipLaunchKernelGGL((stream_gemm_kernel<2, 2, 4, 6, 2, 0>), dim3(bps), dim3(256), 0, 0, Y, F, O, XG, KS, KS, 1, ld, (const int*)nullptr, ca); }, 10);
+            ms = time_ms([&] { hipLaunchKernelGGL((stream_gemm_kernel<2, 2, 4, 6, 2, 0>), dim3(bps), dim3(256), 0, 0, Y, F, O, XG, KS, KS, 1, ld, (const int*)nullptr, ca, 0); }, 10);
             printf("  PRODUCT kernel RCTRL=0 instantiation: %.3f ms %.0f GB/s\n", ms, ybytes / ms / 1e6);
             ms = time_ms([&] { hipLaunchKernelGGL((k_stream2<2, 4, 6, 2, 4, 1, 0>), dim3(bps), dim3(256), 0, 0, Y, F, O, XG, KS, KS, 1, ld); }, 10);
             printf("  harness kernel again               : %.3f ms %.0f GB/s\n", ms, ybytes / ms / 1e6);

@@ -27,9 +27,10 @@ struct StateLayout {
     __host__ __device__ long long KB() const { return 5 * n2(); }     // matrix inverted for SigmaB
     __host__ __device__ long long W0() const { return 6 * n2(); }     // scratch (H > 128)
     __host__ __device__ long long W1() const { return 7 * n2(); }
-    __host__ __device__ long long ca() const { return 8 * n2(); }
-    __host__ __device__ long long cb() const { return 8 * n2() + Hp; }
-    __host__ __device__ long long scal() const { return 8 * n2() + 2 * Hp; }
+    __host__ __device__ long long W2() const { return 8 * n2(); }
+    __host__ __device__ long long ca() const { return 9 * n2(); }
+    __host__ __device__ long long cb() const { return 9 * n2() + Hp; }
+    __host__ __device__ long long scal() const { return 9 * n2() + 2 * Hp; }
     __host__ __device__ long long total() const { return scal() + 32; }
 };
 enum : int { S_SIGMA2 = 0, S_TRYY, S_LOGDET_SA, S_LOGDET_SB, S_LAMB_PREV, S_LAMB_NEW, S_LAMD, S_D, S_ELBO,
@@ -134,6 +135,127 @@ __device__ __forceinline__ void gj_tiled(double (&w)[R][R], int n, double* strip
     }
 }
 
+// ---- 129 <= H <= 256: blocked inverse -----------------------------------------------------------
+// A 256 x 256 fp64 matrix is 512 KB -- the whole register file of a CU -- so the register-tiled sweep
+// above cannot hold it (its 8 x 8 tiles at 1024 threads spill: measured 2.4 ms).  Split K = [A B; B' D] into
+// 128-blocks and use the Schur complement, every piece a 128 x 128 problem that fits:
+//     Ai = inv(A);  W = Ai B;  S = D - B'W;  Si = inv(S);  X12 = -W Si;  X11 = Ai - X12 W';  X22 = Si
+// det K = det A det S, so the pivots of the two sweeps are K's log-determinant.  The two inverses run on the
+// register-tiled sweep (4 x 4 tiles, 1024 threads), the four products on a plain LDS-panelled fp64 GEMM
+// (thread (ty, tx) owns C[4ty..4ty+3][4tx..4tx+3]).  1024 threads; matrices in global memory (L2-resident).
+constexpr int GEMM_LD = 130;   // panel row stride in doubles: 16-byte aligned, rows 4 banks apart
+
+// c += P' Q' over k = 0..127 with P'(i,k) = TP ? P[k*ldp + i] : P[i*ldp + k],  Q'(k,j) = TQ ? Q[j*ldq + k] : Q[k*ldq + j]
+template <bool TP, bool TQ>
+__device__ __forceinline__ void gemm128_acc(double (&c)[4][4], const double* __restrict__ P, int ldp,
+                                            const double* __restrict__ Q, int ldq, double* panel) {
+    double* Ps = panel;
+    double* Qs = panel + 16 * GEMM_LD;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int k0 = 0; k0 < 128; k0 += 16) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int e = threadIdx.x + 1024 * r;
+            if (TP) { const int kk = e >> 7, i = e & 127; Ps[kk * GEMM_LD + i] = P[(long long)(k0 + kk) * ldp + i]; }
+            else    { const int i = e >> 4, kk = e & 15;  Ps[kk * GEMM_LD + i] = P[(long long)i * ldp + k0 + kk]; }
+            if (TQ) { const int j = e >> 4, kk = e & 15;  Qs[kk * GEMM_LD + j] = Q[(long long)j * ldq + k0 + kk]; }
+            else    { const int kk = e >> 7, j = e & 127; Qs[kk * GEMM_LD + j] = Q[(long long)(k0 + kk) * ldq + j]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const double2 a0 = *reinterpret_cast<const double2*>(Ps + kk * GEMM_LD + 4 * ty);
+            const double2 a1 = *reinterpret_cast<const double2*>(Ps + kk * GEMM_LD + 4 * ty + 2);
+            const double2 b0 = *reinterpret_cast<const double2*>(Qs + kk * GEMM_LD + 4 * tx);
+            const double2 b1 = *reinterpret_cast<const double2*>(Qs + kk * GEMM_LD + 4 * tx + 2);
+            const double a[4] = {a0.x, a0.y, a1.x, a1.y}, b[4] = {b0.x, b0.y, b1.x, b1.y};
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < 4; ++y) c[x][y] += a[x] * b[y];
+        }
+    }
+}
+
+// Kg: the SPD matrix, 256 x 256, row stride ld, identity-padded beyond H.  Out: its inverse (same shape).
+// Wm, Sm: 128 x 128 scratch (row stride 128).  lds: 2*16*GEMM_LD + 512 doubles.  pivs: 256 doubles (LDS).
+// Needs 1024 threads; every thread of the block must call it.
+__device__ __forceinline__ void inv256_schur(const double* __restrict__ Kg, double* __restrict__ Out, int ld,
+                                             double* __restrict__ Wm, double* __restrict__ Sm, double* lds,
+                                             double* pivs) {
+    double* panel = lds;
+    double* strip = lds + 2 * 16 * GEMM_LD;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    double w[4][4], c[4][4];
+    // 1. Ai = inv(A) -> Out[0:128, 0:128]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) w[a][b] = Kg[(long long)(ty + 32 * a) * ld + tx + 32 * b];
+    gj_tiled<4, 32>(w, 128, strip, pivs);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) Out[(long long)(ty + 32 * a) * ld + tx + 32 * b] = w[a][b];
+    // 2. W = Ai B
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) c[x][y] = 0.0;
+    gemm128_acc<false, false>(c, Out, ld, Kg + 128, ld, panel);
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) Wm[(4 * ty + x) * 128 + 4 * tx + y] = c[x][y];
+    // 3. S = D - B'W
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) c[x][y] = 0.0;
+    gemm128_acc<true, false>(c, Kg + 128, ld, Wm, 128, panel);
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+            Sm[(4 * ty + x) * 128 + 4 * tx + y] = Kg[(long long)(128 + 4 * ty + x) * ld + 128 + 4 * tx + y] - c[x][y];
+    __syncthreads();
+    // 4. Si = inv(S) -> Out[128:, 128:]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) w[a][b] = Sm[(ty + 32 * a) * 128 + tx + 32 * b];
+    gj_tiled<4, 32>(w, 128, strip, pivs + 128);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) Out[(long long)(128 + ty + 32 * a) * ld + 128 + tx + 32 * b] = w[a][b];
+    // 5. X12 = -W Si (and its transpose)
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) c[x][y] = 0.0;
+    gemm128_acc<false, false>(c, Wm, 128, Out + (long long)128 * ld + 128, ld, panel);
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+            Out[(long long)(4 * ty + x) * ld + 128 + 4 * tx + y] = -c[x][y];
+            Out[(long long)(128 + 4 * tx + y) * ld + 4 * ty + x] = -c[x][y];
+        }
+    // 6. X11 = Ai - X12 W'
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) c[x][y] = 0.0;
+    gemm128_acc<false, true>(c, Out + 128, ld, Wm, 128, panel);
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) Out[(long long)(4 * ty + x) * ld + 4 * tx + y] -= c[x][y];
+    __syncthreads();
+}
+
 // relaxed agent-scope read of the loop's stop flag (bypasses this CU's L1: the flag may have been
 // raised a moment ago by ctrl_end in this very workgroup or by another one)
 __device__ __forceinline__ int load_stop(const int* ints) {
@@ -156,34 +278,60 @@ __device__ __forceinline__ void ctrl_cov_dev(double* __restrict__ st, StateLayou
     const double* cdiag = st + (which == 0 ? lay.ca() : lay.cb());
     double* scal = st + lay.scal();
     const double sigma2 = scal[S_SIGMA2];
-    double w[R][R];
-#pragma unroll
-    for (int a = 0; a < R; ++a)
-#pragma unroll
-        for (int b = 0; b < R; ++b) {
-            const int i = ty + T * a, j = tx + T * b;
+    double* pivs;
+    if constexpr (R == 8 && T == 32) {
+        // 129 <= H <= 256 (Hp = 256): blocked inverse through global scratch (inv256_schur)
+        double* Kg = st + lay.W0();
+        double* Ki = st + lay.W1();
+        for (int t = threadIdx.x; t < 256 * 256; t += 1024) {
+            const int i = t >> 8, j = t & 255;
             double v = (i == j) ? 1.0 : 0.0;                    // identity padding
             if (i < H && j < H) {
                 v = G[(long long)i * Hp + j] + N * Sother[(long long)i * Hp + j];
                 if (i == j) v += sigma2 / cdiag[i];
                 if (which == 1) st[lay.KB() + (long long)i * Hp + j] = v;
             }
-            w[a][b] = v;
+            Kg[t] = v;
         }
-    double* strip = lds;
-    double* pivs = lds + 4 * NP;
-    gj_tiled<R, T>(w, H, strip, pivs);
+        __syncthreads();
+        pivs = lds + 2 * 16 * GEMM_LD + 512;
+        inv256_schur(Kg, Ki, 256, st + lay.W2(), st + lay.W2() + 128 * 128, lds, pivs);
+        for (int t = threadIdx.x; t < 256 * 256; t += 1024) {
+            const int i = t >> 8, j = t & 255;
+            const double v = (i < H && j < H) ? Ki[t] : 0.0;
+            Sself[(long long)i * Hp + j] = sigma2 * v;
+            S32[(long long)i * Hp + j] = (float)v;
+        }
+    } else {
+        double w[R][R];
 #pragma unroll
-    for (int a = 0; a < R; ++a)
+        for (int a = 0; a < R; ++a)
 #pragma unroll
-        for (int b = 0; b < R; ++b) {
-            const int i = ty + T * a, j = tx + T * b;
-            if (i < Hp && j < Hp) {
-                const double v = (i < H && j < H) ? w[a][b] : 0.0;
-                Sself[(long long)i * Hp + j] = sigma2 * v;
-                S32[(long long)i * Hp + j] = (float)v;          // Sigma/sigma2: what the post kernel multiplies by
+            for (int b = 0; b < R; ++b) {
+                const int i = ty + T * a, j = tx + T * b;
+                double v = (i == j) ? 1.0 : 0.0;                    // identity padding
+                if (i < H && j < H) {
+                    v = G[(long long)i * Hp + j] + N * Sother[(long long)i * Hp + j];
+                    if (i == j) v += sigma2 / cdiag[i];
+                    if (which == 1) st[lay.KB() + (long long)i * Hp + j] = v;
+                }
+                w[a][b] = v;
             }
-        }
+        double* strip = lds;
+        pivs = lds + 4 * NP;
+        gj_tiled<R, T>(w, H, strip, pivs);
+#pragma unroll
+        for (int a = 0; a < R; ++a)
+#pragma unroll
+            for (int b = 0; b < R; ++b) {
+                const int i = ty + T * a, j = tx + T * b;
+                if (i < Hp && j < Hp) {
+                    const double v = (i < H && j < H) ? w[a][b] : 0.0;
+                    Sself[(long long)i * Hp + j] = sigma2 * v;
+                    S32[(long long)i * Hp + j] = (float)v;          // Sigma/sigma2: what the post kernel multiplies by
+                }
+            }
+    }
     __syncthreads();
     double ld = 0.0;
     int bad = 0;
@@ -325,15 +473,18 @@ __global__ __launch_bounds__(256) void eig_kernel(double* __restrict__ st, State
     eig_dev<R>(st, lay, H, spectral, which, ints, lds_eig, which == 0 ? S_LAMD : S_LAMB_NEW);
 }
 
-// Fallback for H > 128 (the squaring kernel's two LDS tiles do not fit): 1024 threads, fp64 power iteration
-// on the matrix in global memory (L2-resident) with a Rayleigh quotient at the end.  Converges like
-// (lambda_2/lambda_1)^(2k) in the quotient; EIG_POWER_ITERS fixed, so near-degenerate top eigenvalues are
-// only resolved to ~1e-3 -- accepted for this slow path (d is a stopping heuristic), stated in DESIGN.md.
-constexpr int EIG_POWER_ITERS = 96;
+// H > 128 (the squaring kernel's two LDS tiles do not fit): power iteration with the matrix held in REGISTERS.
+// 1024 threads; thread (row = t/4, q = t%4) keeps G[row][64q .. 64q+63] / tr as 64 floats, the vector lives
+// in LDS (double-buffered: one barrier per iteration, normalised every 4th).  lambda = Rayleigh quotient of the
+// final vector, accumulated in fp64.  Converges like (lambda_2/lambda_1)^(2k) in the quotient;
+// EIG_POWER_ITERS fixed, so near-degenerate top eigenvalues are only resolved to ~1e-3 -- accepted (d is a
+// stopping heuristic), stated in DESIGN.md.  (The first version walked the fp64 matrix in global memory every
+// iteration: 31 us per iteration, 3 ms per call at H = 256; this one is ~0.5 us per iteration.)
+constexpr int EIG_POWER_ITERS = 128;
 __global__ __launch_bounds__(1024) void eig_power_kernel(double* __restrict__ st, StateLayout lay, int H, int spectral,
                                                          int do_d, int do_b, const int* __restrict__ ints) {
     __shared__ double red[16];
-    __shared__ double v0[256], v1[256];
+    __shared__ __attribute__((aligned(16))) float vbuf[2][256];
     if (load_stop(ints)) return;
     const int which = blockIdx.x;           // 0: GD, 1: GB
     if ((which == 0 && !do_d) || (which == 1 && !do_b)) return;
@@ -348,33 +499,50 @@ __global__ __launch_bounds__(1024) void eig_power_kernel(double* __restrict__ st
         if (threadIdx.x == 0) scal[slot] = tr;
         return;
     }
-    // start from the diagonal (a positive vector correlated with the dominant eigenvector of a PSD matrix)
-    for (int i = threadIdx.x; i < H; i += blockDim.x) v0[i] = G[(long long)i * Hp + i] / tr + 1e-3;
-    __syncthreads();
     const int row = threadIdx.x >> 2, q = threadIdx.x & 3;      // 4 threads per row, 256 rows
-    double lam = 0.0;
+    float g[64];
+    {
+        const double inv = 1.0 / tr;                            // |G_ij| <= tr: entries in [-1, 1]
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+            const int col = q * 64 + j;
+            g[j] = (row < H && col < H) ? (float)(G[(long long)row * Hp + col] * inv) : 0.f;
+        }
+    }
+    // start from the diagonal (a positive vector correlated with the dominant eigenvector of a PSD matrix)
+    if (threadIdx.x < 256) vbuf[0][threadIdx.x] = threadIdx.x < H ? (float)(G[(long long)threadIdx.x * Hp + threadIdx.x] / tr) + 1e-3f : 0.f;
+    __syncthreads();
+    int cur = 0;
     for (int it = 0; it < EIG_POWER_ITERS; ++it) {
-        double acc = 0.0;
-        if (row < H) {
-            const int jn = (H + 3) / 4, j0 = q * jn, j1 = min(H, j0 + jn);
-            for (int j = j0; j < j1; ++j) acc += G[(long long)row * Hp + j] * v0[j];
+        const float4* v4 = reinterpret_cast<const float4*>(&vbuf[cur][q * 64]);
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float4 v = v4[j];
+            acc += g[4 * j] * v.x + g[4 * j + 1] * v.y + g[4 * j + 2] * v.z + g[4 * j + 3] * v.w;
         }
         acc += __shfl_xor(acc, 1);
         acc += __shfl_xor(acc, 2);
-        double num = 0.0, den = 0.0;
-        if (row < H && q == 0) { v1[row] = acc; num = v0[row] * acc; den = v0[row] * v0[row]; }
-        num = block_sum(num, red);
-        den = block_sum(den, red);
-        lam = den > 0.0 ? num / den : 0.0;
-        double n1 = 0.0;
-        if (row < H && q == 0) n1 = acc * acc;
-        n1 = block_sum(n1, red);
-        const double sc = n1 > 0.0 ? 1.0 / sqrt(n1) : 0.0;
+        if ((it & 3) == 3) {                                    // entries shrink by >= 1/256 per step: safe for 4
+            double n1 = (q == 0) ? (double)acc * (double)acc : 0.0;
+            n1 = block_sum(n1, red);
+            acc = n1 > 0.0 ? (float)((double)acc / sqrt(n1)) : 0.f;
+        }
+        if (q == 0) vbuf[cur ^ 1][row] = acc;
         __syncthreads();
-        for (int i = threadIdx.x; i < H; i += blockDim.x) v0[i] = v1[i] * sc;
-        __syncthreads();
+        cur ^= 1;
     }
-    if (threadIdx.x == 0) scal[slot] = lam;
+    // Rayleigh quotient v'Gv / v'v, fp64 accumulation
+    double gv = 0.0;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) gv += (double)g[j] * (double)vbuf[cur][q * 64 + j];
+    gv += __shfl_xor(gv, 1);
+    gv += __shfl_xor(gv, 2);
+    const double vi = (double)vbuf[cur][row];
+    double num = (q == 0) ? vi * gv : 0.0, den = (q == 0) ? vi * vi : 0.0;
+    num = block_sum(num, red);
+    den = block_sum(den, red);
+    if (threadIdx.x == 0) scal[slot] = den > 0.0 ? tr * num / den : 0.0;
 }
 
 // flags: bit0 est_covs->CA, bit1 est_covs->CB, bit2 est_var, bit3 compute d + loop bookkeeping,

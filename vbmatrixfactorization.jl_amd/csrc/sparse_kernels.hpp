@@ -106,34 +106,60 @@ __global__ __launch_bounds__(T * T) void sparse_cov_b_kernel(double* __restrict_
     double* scal = st + lay.scal();
     const double sig = scal[S_SIGMA2];
     const double* cb = st + lay.cb();
-    double w[R][R];
-#pragma unroll
-    for (int a = 0; a < R; ++a)
-#pragma unroll
-        for (int b = 0; b < R; ++b) {
-            const int i = ty + T * a, j = tx + T * b;
+    double* pivs;
+    if constexpr (R == 8 && T == 32) {
+        // 129 <= H <= 256 (Hp = 256): blocked inverse through global scratch (inv256_schur, ctrl_kernels.hpp)
+        double* Kg = st + lay.W0();
+        double* Ki = st + lay.W1();
+        for (int t = threadIdx.x; t < 256 * 256; t += 1024) {
+            const int i = t >> 8, j = t & 255;
             double v = (i == j) ? 1.0 : 0.0;
             if (i < H && j < H) {
                 v = sig * (st[lay.GA() + (long long)i * Hp + j] + st[lay.SA() + (long long)i * Hp + j]);
                 if (i == j) v += cb[i];
                 st[lay.KB() + (long long)i * Hp + j] = v / sig;
             }
-            w[a][b] = v;
+            Kg[t] = v;
         }
-    double* strip = lds_scb;
-    double* pivs = lds_scb + 4 * NP;
-    gj_tiled<R, T>(w, H, strip, pivs);
+        __syncthreads();
+        pivs = lds_scb + 2 * 16 * GEMM_LD + 512;
+        inv256_schur(Kg, Ki, 256, st + lay.W2(), st + lay.W2() + 128 * 128, lds_scb, pivs);
+        for (int t = threadIdx.x; t < 256 * 256; t += 1024) {
+            const int i = t >> 8, j = t & 255;
+            const double v = (i < H && j < H) ? Ki[t] : 0.0;
+            st[lay.SB() + (long long)i * Hp + j] = v;
+            S32[(long long)i * Hp + j] = (float)(sig * v);
+        }
+    } else {
+        double w[R][R];
 #pragma unroll
-    for (int a = 0; a < R; ++a)
+        for (int a = 0; a < R; ++a)
 #pragma unroll
-        for (int b = 0; b < R; ++b) {
-            const int i = ty + T * a, j = tx + T * b;
-            if (i < Hp && j < Hp) {
-                const double v = (i < H && j < H) ? w[a][b] : 0.0;
-                st[lay.SB() + (long long)i * Hp + j] = v;
-                S32[(long long)i * Hp + j] = (float)(sig * v);
+            for (int b = 0; b < R; ++b) {
+                const int i = ty + T * a, j = tx + T * b;
+                double v = (i == j) ? 1.0 : 0.0;
+                if (i < H && j < H) {
+                    v = sig * (st[lay.GA() + (long long)i * Hp + j] + st[lay.SA() + (long long)i * Hp + j]);
+                    if (i == j) v += cb[i];
+                    st[lay.KB() + (long long)i * Hp + j] = v / sig;
+                }
+                w[a][b] = v;
             }
-        }
+        double* strip = lds_scb;
+        pivs = lds_scb + 4 * NP;
+        gj_tiled<R, T>(w, H, strip, pivs);
+#pragma unroll
+        for (int a = 0; a < R; ++a)
+#pragma unroll
+            for (int b = 0; b < R; ++b) {
+                const int i = ty + T * a, j = tx + T * b;
+                if (i < Hp && j < Hp) {
+                    const double v = (i < H && j < H) ? w[a][b] : 0.0;
+                    st[lay.SB() + (long long)i * Hp + j] = v;
+                    S32[(long long)i * Hp + j] = (float)(sig * v);
+                }
+            }
+    }
     __syncthreads();
     double ld = 0.0;
     int bad = 0;

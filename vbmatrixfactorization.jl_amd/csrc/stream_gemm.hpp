@@ -48,10 +48,11 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const uint4* __restric
                                                           float* __restrict__ Out,        // [nsplit][NH*32][ldOut]
                                                           int XG, int KS, int steps_per_split, int nsplit,
                                                           long long ldOut, const int* __restrict__ stop,
-                                                          CtrlArgs ctrl) {
+                                                          CtrlArgs ctrl, int xcd_xb) {
     constexpr int NPART = ModeTraits<MODE>::NPART;
     constexpr int NF = NPART * NH;
     static_assert(PIPE_D % DY == 0 && DY % DF == 0, "ring depths must divide the padding quantum");
+    constexpr bool FINE = (NH >= 4);
     int bid = blockIdx.x;
     if (ctrl.mode != 0) {                                 // launch carries a control workgroup (dispatched first)
         if (bid == 0) {
@@ -68,8 +69,20 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const uint4* __restric
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform => SGPR addressing
     const int bps = (XG + 3) >> 2;                       // blocks per split
-    const int split = bid / bps;
-    const int xg = (bid % bps) * 4 + wib;
+    int split, xb;
+    if (xcd_xb > 0) {
+        // XCD-aware map for split launches whose factor stream is large (H >= 128): workgroups are dealt
+        // round-robin to the 8 XCDs, so group g = bid % 8 owns x blocks [g*xcd_xb, (g+1)*xcd_xb) for EVERY
+        // split: the xcd_xb workgroups that share a split's factor k-range sit behind the same L2.
+        const int g = bid & 7, j = bid >> 3;
+        xb = g * xcd_xb + j % xcd_xb;
+        split = j / xcd_xb;
+        if (xb >= bps) return;
+    } else {
+        split = bid / bps;
+        xb = bid % bps;
+    }
+    const int xg = xb * 4 + wib;
     if (xg >= XG || split >= nsplit) return;              // wave-uniform
 
     const long long ks0 = (long long)split * steps_per_split;
@@ -109,49 +122,81 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const uint4* __restric
             constexpr int UNUSED = 0; (void)UNUSED;
             const int fd = d % DF;
             // consume Y slot d and factor slot d % DF (lead-in iterations multiply zeros) ...
-            if constexpr (MODE == MODE_F32) {
+            if constexpr (FINE) {
+                // H >= 128: a k-step is 32 MFMAs (~1000 cycles) on NF factor fragments.  Refill every factor
+                // fragment right after ITS MFMAs (not after the whole step), so the DF-deep ring really
+                // gives DF k-steps of L2 latency to each fragment; the Y fragments follow their last use.
 #pragma unroll
-                for (int h = 0; h < NH; ++h) {
-                    const f32x4 fe = __builtin_bit_cast(f32x4, fb[fd][h]);
+                for (int j = 0; j < NF; ++j) {
+                    if constexpr (MODE == MODE_F32) {
+                        const f32x4 fe = __builtin_bit_cast(f32x4, fb[fd][j]);
 #pragma unroll
-                    for (int i = 0; i < NXW_; ++i) {
-                        const f32x4 ye = __builtin_bit_cast(f32x4, yb[d][i]);
+                        for (int i = 0; i < NXW_; ++i) {
+                            const f32x4 ye = __builtin_bit_cast(f32x4, yb[d][i]);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            acc[i][h] = __builtin_amdgcn_mfma_f32_32x32x2f32(fe[e], ye[e], acc[i][h], 0, 0, 0);
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int p = 0; p < NPART; ++p)
-#pragma unroll
-                    for (int h = 0; h < NH; ++h) {
-                        const bf16x8 fa = __builtin_bit_cast(bf16x8, fb[fd][p * NH + h]);
+                            for (int e = 0; e < 4; ++e)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fe[e], ye[e], acc[i][j], 0, 0, 0);
+                        }
+                    } else {
+                        const bf16x8 fa = __builtin_bit_cast(bf16x8, fb[fd][j]);
 #pragma unroll
                         for (int i = 0; i < NXW_; ++i)
-                            acc[i][h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                                fa, __builtin_bit_cast(bf16x8, yb[d][i]), acc[i][h], 0, 0, 0);
+                            acc[i][j % NH] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                fa, __builtin_bit_cast(bf16x8, yb[d][i]), acc[i][j % NH], 0, 0, 0);
                     }
+                    fb[fd][j] = __builtin_amdgcn_raw_buffer_load_b128(fr, voff, ((s + d + DF) * NF + j) * 1024, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, NXW_ * (MODE == MODE_F32 ? 4 : 1), 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < NXW_; ++i)
+                    yb[d][i] = __builtin_amdgcn_raw_buffer_load_b128(yr[i], voff, (s + DY + d) * 1024, Y_AUX);
+                __builtin_amdgcn_sched_group_barrier(0x020, NXW_, 0);
+            } else {
+                if constexpr (MODE == MODE_F32) {
+    #pragma unroll
+                    for (int h = 0; h < NH; ++h) {
+                        const f32x4 fe = __builtin_bit_cast(f32x4, fb[fd][h]);
+    #pragma unroll
+                        for (int i = 0; i < NXW_; ++i) {
+                            const f32x4 ye = __builtin_bit_cast(f32x4, yb[d][i]);
+    #pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                acc[i][h] = __builtin_amdgcn_mfma_f32_32x32x2f32(fe[e], ye[e], acc[i][h], 0, 0, 0);
+                        }
+                    }
+                } else {
+    #pragma unroll
+                    for (int p = 0; p < NPART; ++p)
+    #pragma unroll
+                        for (int h = 0; h < NH; ++h) {
+                            const bf16x8 fa = __builtin_bit_cast(bf16x8, fb[fd][p * NH + h]);
+    #pragma unroll
+                            for (int i = 0; i < NXW_; ++i)
+                                acc[i][h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                    fa, __builtin_bit_cast(bf16x8, yb[d][i]), acc[i][h], 0, 0, 0);
+                        }
+                }
+                // ... and refill both at once (Y: step +DY, factor: step +DF).  MFMAs read their operands at
+                // issue and a wave issues in order, so the refill may target the registers just consumed.
+                // The lead-in's factor steps are negative: they read the previous split's tiles or the PIPE_D
+                // zero tiles in FRONT of the factor buffer (finite data times the zero Y ring).  The run-ahead
+                // past the split lands in the next split's tiles or in the trailing slack and is never
+                // consumed.  Nothing relies on the descriptor's bounds check (the SGPR offset is not part of
+                // it).  (Clamping the lead-in step with max(.,0) instead cost 12 %: hipcc peels the lead-in
+                // iteration and its waits serialise every wave's pipeline fill.)
+    #pragma unroll
+                for (int i = 0; i < NXW_; ++i)
+                    yb[d][i] = __builtin_amdgcn_raw_buffer_load_b128(yr[i], voff, (s + DY + d) * 1024, Y_AUX);
+    #pragma unroll
+                for (int j = 0; j < NF; ++j)
+                    fb[fd][j] = __builtin_amdgcn_raw_buffer_load_b128(fr, voff, ((s + d + DF) * NF + j) * 1024, 0);
+                // pin that order in the emitted stream (otherwise hipcc sinks every refill to the loop bottom
+                // and drains vmcnt(0) each iteration)
+                constexpr int NMFMA = NXW_ * NF * (MODE == MODE_F32 ? 4 : 1);
+                __builtin_amdgcn_sched_group_barrier(0x008, NMFMA, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, NXW_ + NF, 0);
             }
-            // ... and refill both at once (Y: step +DY, factor: step +DF).  MFMAs read their operands at
-            // issue and a wave issues in order, so the refill may target the registers just consumed.
-            // The lead-in's factor steps are negative: they read the previous split's tiles or the PIPE_D
-            // zero tiles in FRONT of the factor buffer (finite data times the zero Y ring).  The run-ahead
-            // past the split lands in the next split's tiles or in the trailing slack and is never
-            // consumed.  Nothing relies on the descriptor's bounds check (the SGPR offset is not part of
-            // it).  (Clamping the lead-in step with max(.,0) instead cost 12 %: hipcc peels the lead-in
-            // iteration and its waits serialise every wave's pipeline fill.)
-#pragma unroll
-            for (int i = 0; i < NXW_; ++i)
-                yb[d][i] = __builtin_amdgcn_raw_buffer_load_b128(yr[i], voff, (s + DY + d) * 1024, Y_AUX);
-#pragma unroll
-            for (int j = 0; j < NF; ++j)
-                fb[fd][j] = __builtin_amdgcn_raw_buffer_load_b128(fr, voff, ((s + d + DF) * NF + j) * 1024, 0);
-            // pin that order in the emitted stream (otherwise hipcc sinks every refill to the loop bottom
-            // and drains vmcnt(0) each iteration)
-            constexpr int NMFMA = NXW_ * NF * (MODE == MODE_F32 ? 4 : 1);
-            __builtin_amdgcn_sched_group_barrier(0x008, NMFMA, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, NXW_ + NF, 0);
         }
     }
 

@@ -147,16 +147,18 @@ static inline int grid_for(int64_t n, int block = 256, int cap = 8192) {
     return (int)std::max<int64_t>(1, std::min<int64_t>((n + block - 1) / block, cap));
 }
 
-// per-NH geometry of the streaming kernel: NXW * NH = 8 accumulator tiles (128 registers) per wave,
-// Y ring DY and factor ring DF k-steps deep (register budget: 128 + 4*(DY*NXW + DF*NF) + addressing)
+// per-NH geometry of the streaming kernel: NXW * NH accumulator tiles per wave -- 8 (128 registers) up to H = 64,
+// 16 (all 256 AGPRs) from H = 128 on, where the factor operand's L2->L1 traffic per Y byte is what limits a CU
+// (measured, scripts/bigh_tune.hip: H=128 0.64 -> 0.51 ms per 2.5 GB pass, H=256 1.48 -> 0.83 ms per 2 GB pass);
+// Y ring DY and factor ring DF k-steps deep (VGPR budget: 4*(DY*NXW + DF*NF) + addressing)
 template <int NH> struct StreamCfg;
 template <> struct StreamCfg<1> { static constexpr int NXWc = 8; static constexpr int DYc = 3; static constexpr int DFc = 3; static constexpr int Rc = 2; };
 template <> struct StreamCfg<2> { static constexpr int NXWc = 4; static constexpr int DYc = 6; static constexpr int DFc = 2; static constexpr int Rc = 4; };
-template <> struct StreamCfg<4> { static constexpr int NXWc = 2; static constexpr int DYc = 6; static constexpr int DFc = 2; static constexpr int Rc = 8; };
-template <> struct StreamCfg<8> { static constexpr int NXWc = 1; static constexpr int DYc = 4; static constexpr int DFc = 1; static constexpr int Rc = 0; };
+template <> struct StreamCfg<4> { static constexpr int NXWc = 4; static constexpr int DYc = 4; static constexpr int DFc = 2; static constexpr int Rc = 8; };
+template <> struct StreamCfg<8> { static constexpr int NXWc = 2; static constexpr int DYc = 2; static constexpr int DFc = 2; static constexpr int Rc = 0; };
 
-static int nxw_of(int NH) { return 8 / NH; }
-static int dy_of(int NH) { return NH == 1 ? 3 : (NH == 8 ? 4 : 6); }    // = StreamCfg<NH>::DYc
+static int nxw_of(int NH) { return NH == 1 ? 8 : (NH == 8 ? 2 : 4); }              // = StreamCfg<NH>::NXWc
+static int dy_of(int NH) { return NH == 1 ? 3 : (NH == 2 ? 6 : (NH == 4 ? 4 : 2)); } // = StreamCfg<NH>::DYc
 // one CU is left to the control workgroup that rides in each pass launch
 constexpr int NUM_CU = 255;
 
@@ -175,7 +177,9 @@ static void plan_pass(Dims& d, int64_t X, int64_t K, int kstep, int NH, int Hp, 
     const int bps = (XG + 3) / 4;
     int ns = want_splits;
     if (ns <= 0) {
-        const double R_CU = 24e9, R_HBM = 5.4e12;   // measured in the sweep pipeline (200 vs 240 blocks: 0.434 vs 0.390 ms)
+        // measured in the sweep pipeline (H=64: 200 vs 240 blocks 0.434 vs 0.390 ms); a CU's rate falls with H
+        // (more MFMA work and factor traffic per Y byte): H=128 ~20 GB/s, H=256 ~10 GB/s (scripts/bigh_tune.hip)
+        const double R_CU = NH <= 2 ? 24e9 : (NH == 4 ? 20e9 : 10e9), R_HBM = 5.4e12;
         const double total = (double)d.XT * 32.0 * (double)ks_min * kstep * ybytes;
         const double out_bytes = (double)Hp * d.XT * 32.0 * 4.0;
         const int ns_max = (int)std::max<int64_t>(1, std::min<int64_t>(64, ks_min / (2 * kq)));
@@ -253,7 +257,7 @@ static int launch_stream(vbmf_ctx* c, int pass, int ctrl_mode = 0) {
     DISPATCH_MODE(c->mode, DISPATCH_NH(c->NH, {
         using Cfg = StreamCfg<NHc>;
         hipLaunchKernelGGL((stream_gemm_kernel<MODEc, NHc, Cfg::NXWc, Cfg::DYc, Cfg::DFc, Cfg::Rc>), dim3(grid), dim3(256), lds,
-                           c->stream, Y, F, out, XG, d.KS, d.steps_per_split, d.nsplit, ld, c->ints + I_STOP, ca);
+                           c->stream, Y, F, out, XG, d.KS, d.steps_per_split, d.nsplit, ld, c->ints + I_STOP, ca, 0);
     }));
     prof_end(c);
     HIPCHK(c, hipGetLastError());
@@ -360,7 +364,7 @@ static hipStream_t ctrl_stream(vbmf_ctx* c) { return c->stream; }
 
 template <int R, int T>
 static void launch_cov_t(vbmf_ctx* c, int which, hipStream_t s) {
-    const size_t lds = (size_t)(5 * T * R) * sizeof(double);
+    const size_t lds = (R == 8 && T == 32) ? (size_t)(2 * 16 * GEMM_LD + 512 + 256) * sizeof(double) : (size_t)(5 * T * R) * sizeof(double);
     const double N = which == 0 ? (double)c->Lg : (double)c->M;
     hipLaunchKernelGGL((ctrl_cov_kernel<R, T>), dim3(1), dim3(T * T), lds, s, c->st, c->lay, (int)c->H, which, N,
                        which == 0 ? c->SA32 : c->SB32, c->ints);
@@ -1193,7 +1197,7 @@ static double digamma_host(double x) {
 
 template <int R, int T>
 static void launch_scov_t(vbmf_ctx* c) {
-    const size_t lds = (size_t)(5 * T * R) * sizeof(double);
+    const size_t lds = (R == 8 && T == 32) ? (size_t)(2 * 16 * GEMM_LD + 512 + 256) * sizeof(double) : (size_t)(5 * T * R) * sizeof(double);
     hipLaunchKernelGGL((sparse_cov_b_kernel<R, T>), dim3(1), dim3(T * T), lds, c->stream, c->st, c->lay, (int)c->H, c->SB32, c->ints);
 }
 static int launch_sparse_cov_b(vbmf_ctx* c) {
