@@ -20,6 +20,7 @@
 #ifndef VBMF_HIP_H
 #define VBMF_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -157,6 +158,12 @@ int vbmf_sparse_lower_bound(vbmf_ctx* ctx, int clamp, double* lb);
 #define VBMF_UNIQUE_ID_BYTES 128
 int vbmf_comm_unique_id(void* id128);                       /* rank 0 creates, host broadcasts */
 int vbmf_comm_init(vbmf_ctx* ctx, const void* id128);       /* collective over all nranks ctxs */
+/* Bring-up / test transport INSTEAD of RCCL: fn must sum `count` floats (is_double = 0) or doubles (1) of the DEVICE
+ * buffer `buf` over all ranks in place, ordered after everything already enqueued on `hip_stream` and complete
+ * (or stream-ordered) on return; returns 0 on success.  Lets N ranks share one GPU over a host-staged reduction
+ * (tests/test_gpu_two_ranks.py), which RCCL refuses ("Duplicate GPU detected").  Not a performance path. */
+typedef int (*vbmf_allreduce_fn)(void* user, void* buf, size_t count, int is_double, void* hip_stream);
+int vbmf_comm_set_transport(vbmf_ctx* ctx, vbmf_allreduce_fn fn, void* user);
 
 /* ---- measurement hooks (bench.py): HIP-event timing of the two streaming kernels ---- */
 int vbmf_profile_enable(vbmf_ctx* ctx, int on);

@@ -1,0 +1,95 @@
+"""Row-sharded sweep with MORE THAN ONE RANK on the real kernels.
+
+The GPU box of the test tier has one GPU and RCCL refuses two ranks on one device, so the two-rank test swaps
+the library's transport (vbmf_comm_set_transport) for a host-staged gloo all-reduce: everything else -- the
+row-sharded tiling, L_global in the H x H algebra, the all-reduce points (Y'B partial, packed Grams, ||Y||^2),
+the gated copies, the replicated state and the device-side stop flag -- is the production code path.  The RCCL
+calls themselves are covered by the single-rank communicator test (test_gpu_parity.py) and, on a box with two or
+more GPUs, by test_two_gpus_rccl below (skipped otherwise)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as G
+from tests import two_rank_worker as W
+from tests.helpers import relF, report
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    G.build()
+    return G.load_package()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _spawn(world, transport, outdir):
+    port = _free_port()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "two_rank_worker.py"), str(r), str(world),
+                               str(port), str(outdir), transport], env=env, cwd=ROOT) for r in range(world)]
+    try:
+        rcs = [p.wait(timeout=240) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert rcs == [0] * world, rcs
+    return [dict(np.load(os.path.join(outdir, f"rank{r}.npz"))) for r in range(world)]
+
+
+def _check(pkg, world, transport, tmp_path):
+    L, M, H = W.SHAPE
+    Y, A0, B0 = W.problem(L, M, H, W.SEED)
+    with pkg.capi.Context(L, M, H, y_dtype=pkg.VBMF_Y_BF16) as c:
+        ref = W.run(pkg, c, Y, A0, B0, H)
+    ranks = _spawn(world, transport, tmp_path)
+    # replicated quantities are bit-identical across the ranks (they see the same reduced sums)
+    for k in ("AHat", "SigmaA", "SigmaB", "CA_diag", "CB_diag", "sigma2", "d", "trace", "trYY", "it"):
+        for r in ranks[1:]:
+            assert np.array_equal(ranks[0][k], r[k]), k
+    B = np.concatenate([r["BHat"] for r in ranks], axis=0)
+    assert [int(r["row0"]) for r in ranks] == [pkg.dist.row_shard(L, world, i)[0] for i in range(world)]
+    assert B.shape == (L, H) and int(ranks[0]["it"]) == ref["it"] == W.NITER
+    errs = dict(A=relF(ranks[0]["AHat"], ref["AHat"]), B=relF(B, ref["BHat"]),
+                SA=relF(ranks[0]["SigmaA"], ref["SigmaA"]), SB=relF(ranks[0]["SigmaB"], ref["SigmaB"]),
+                ca=relF(ranks[0]["CA_diag"], ref["CA_diag"]), cb=relF(ranks[0]["CB_diag"], ref["CB_diag"]),
+                s2=abs(float(ranks[0]["sigma2"]) - ref["sigma2"]) / ref["sigma2"],
+                trYY=abs(float(ranks[0]["trYY"]) - ref["trYY"]) / ref["trYY"],
+                d=abs(float(ranks[0]["d"]) - ref["d"]) / ref["d"],
+                elbo=abs(float(ranks[0]["elbo"]) - ref["elbo"]) / abs(ref["elbo"]))
+    report(f"{world} ranks ({transport} transport) vs 1 rank, {L}x{M} H={H}, {W.NITER} sweeps: "
+           + " ".join(f"{k}={v:.2e}" for k, v in errs.items()))
+    # same arithmetic, different summation order of the row partials (fp32 partial sums of Y'B, fp64 Grams).
+    # sigma2 is the reference's cancelling difference ||Y||^2 - 2tr + tr (x ~400 here), and SigmaA/SigmaB scale
+    # with it, so those see the fp32 reordering noise amplified; d is a difference of fp32-stored factors.
+    assert max(errs[k] for k in ("A", "B", "ca", "cb")) < 2e-5, errs
+    assert max(errs[k] for k in ("SA", "SB", "s2")) < 5e-4, errs
+    assert errs["trYY"] < 1e-12 and errs["elbo"] < 1e-4, errs
+    assert abs(float(ranks[0]["d"]) - ref["d"]) < 2e-2 * ref["d"] + 2e-6, errs
+
+
+def test_two_ranks_one_gpu_host_transport(pkg, tmp_path):
+    _check(pkg, 2, "host", tmp_path)
+
+
+def test_three_ranks_one_gpu_host_transport(pkg, tmp_path):
+    _check(pkg, 3, "host", tmp_path)
+
+
+def test_two_gpus_rccl(pkg, tmp_path):
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    _check(pkg, 2, "rccl", tmp_path)

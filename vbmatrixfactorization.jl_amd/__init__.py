@@ -30,7 +30,7 @@ from typing import Optional
 
 import numpy as np
 
-from . import capi
+from . import capi, dist
 from .capi import (Context, VbmfError, VBMF_Y_F32, VBMF_Y_BF16, VBMF_FACTOR_AUTO, VBMF_FACTOR_BF16,
                    VBMF_FACTOR_BF16X2, VBMF_VARIANT_SPARSE_DIAG, STEP_A, STEP_B, STEP_CA, STEP_CB, STEP_SIGMA2,
                    SSTEP_A, SSTEP_B, SSTEP_CA, SSTEP_CB, SSTEP_SIGMA)

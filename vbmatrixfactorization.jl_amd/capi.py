@@ -22,7 +22,7 @@ UNIQUE_ID_BYTES = 128
 SYMBOLS = [
     "vbmf_default_opts", "vbmf_create", "vbmf_destroy", "vbmf_last_error", "vbmf_set_Y", "vbmf_set_Y_synthetic",
     "vbmf_get_Y", "vbmf_get_trYY", "vbmf_set_state", "vbmf_get_state", "vbmf_step", "vbmf_run", "vbmf_get_YHat",
-    "vbmf_elbo", "vbmf_comm_unique_id", "vbmf_comm_init", "vbmf_profile_enable", "vbmf_profile_read",
+    "vbmf_elbo", "vbmf_comm_unique_id", "vbmf_comm_init", "vbmf_comm_set_transport", "vbmf_profile_enable", "vbmf_profile_read",
     "vbmf_pass_bytes", "vbmf_device_sync", "vbmf_debug_peek", "vbmf_debug_time_pass",
     "vbmf_sparse_set_state", "vbmf_sparse_get_state", "vbmf_sparse_step", "vbmf_sparse_run", "vbmf_sparse_lower_bound",
 ]
@@ -41,6 +41,10 @@ class VbmfOpts(C.Structure):
 class VbmfSparseHyper(C.Structure):
     _fields_ = [("alpha0", C.c_double), ("beta0", C.c_double), ("gamma0", C.c_double), ("delta0", C.c_double),
                 ("eta0", C.c_double), ("zeta0", C.c_double)]
+
+
+# int fn(void* user, void* buf, size_t count, int is_double, void* hip_stream)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
 
 
 class VbmfError(RuntimeError):
@@ -90,6 +94,7 @@ def lib():
     L.vbmf_elbo.argtypes = [vp, dp]
     L.vbmf_comm_unique_id.argtypes = [vp]
     L.vbmf_comm_init.argtypes = [vp, vp]
+    L.vbmf_comm_set_transport.argtypes = [vp, ALLREDUCE_FN, vp]
     L.vbmf_profile_enable.argtypes = [vp, i32]
     L.vbmf_profile_read.argtypes = [vp, dp, i32]
     L.vbmf_pass_bytes.argtypes = [vp, i32, dp]
@@ -277,6 +282,19 @@ class Context:
     def comm_init(self, uid):
         buf = C.create_string_buffer(bytes(uid), UNIQUE_ID_BYTES)
         self._chk(self._lib.vbmf_comm_init(self._h, buf))
+
+    def comm_set_transport(self, fn):
+        """Bring-up transport instead of RCCL: fn(buf_ptr, count, is_double, stream_ptr) -> 0 sums a device buffer
+        over the ranks in place (see include/vbmf_hip.h).  The ctypes thunk is kept alive with the context."""
+        def thunk(user, buf, count, is_double, stream):
+            try:
+                return int(fn(buf, count, bool(is_double), stream) or 0)
+            except Exception:            # never let a Python exception unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._ar_thunk = ALLREDUCE_FN(thunk)
+        self._chk(self._lib.vbmf_comm_set_transport(self._h, self._ar_thunk, None))
 
     # ---- measurement ----
     def profile_enable(self, on=True):

@@ -613,7 +613,7 @@ __device__ __forceinline__ void ctrl_end_dev(double* __restrict__ st, StateLayou
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void ctrl_end_kernel(double* __restrict__ st, StateLayout lay, int H, double Lg,
+__global__ __launch_bounds__(1024) void ctrl_end_kernel(double* __restrict__ st, StateLayout lay, int H, double Lg,
                                                        double M, int flags, double eps,
                                                        double* __restrict__ trace, int* __restrict__ ints) {
     ctrl_end_dev(st, lay, H, Lg, M, flags, eps, trace, ints);

@@ -73,22 +73,51 @@ __global__ __launch_bounds__(256) void sparse_update_ca_kernel(const float* __re
     }
 }
 
-// out[h] = sum_m X[m][h]  (fp64, one block per 32 columns, fixed order)
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, long long M, int H, int Hp,
-                                                     double* __restrict__ st, StateLayout lay) {
+// SigmaA[h][h] = sum_m X[m][h] (src/vbmf_sparse.jl:236-239), fp64, fixed order, two stages:
+// grid (Hp/32, COLSUM_CHUNKS) partial sums over row chunks, then one block per 32 columns folds the chunks.
+// (One block per 32 columns walking all M rows was latency-bound: 321 us at M = 10 000, H = 256.)
+constexpr int COLSUM_CHUNKS = 32;
+__global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restrict__ X, long long M, int H, int Hp,
+                                                          double* __restrict__ part /* [COLSUM_CHUNKS][Hp] */) {
     __shared__ double sh[8][32];
     const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
     const int h = blockIdx.x * 32 + c;
-    double a = 0.0;
-    if (h < H)
-        for (long long m = g; m < M; m += 8) a += (double)X[m * Hp + h];
-    sh[g][c] = a;
+    const long long rows = (M + COLSUM_CHUNKS - 1) / COLSUM_CHUNKS;
+    const long long m0 = (long long)blockIdx.y * rows, m1 = m0 + rows < M ? m0 + rows : M;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (h < H) {
+        long long m = m0 + g;
+        for (; m + 24 < m1; m += 32) {
+            a0 += (double)X[m * Hp + h];
+            a1 += (double)X[(m + 8) * Hp + h];
+            a2 += (double)X[(m + 16) * Hp + h];
+            a3 += (double)X[(m + 24) * Hp + h];
+        }
+        for (; m < m1; m += 8) a0 += (double)X[m * Hp + h];
+    }
+    sh[g][c] = (a0 + a1) + (a2 + a3);
     __syncthreads();
-    if (g == 0 && h < Hp) {
+    if (g == 0) {
         double s = 0.0;
         for (int q = 0; q < 8; ++q) s += sh[q][c];
-        // SigmaA is diagonal here: write the full row so stale off-diagonals never survive
-        for (int j = 0; j < Hp; ++j) st[lay.SA() + (long long)h * Hp + j] = (j == h && h < H) ? s : 0.0;
+        part[(long long)blockIdx.y * Hp + h] = s;
+    }
+}
+__global__ __launch_bounds__(256) void colsum_fold_kernel(const double* __restrict__ part, int H, int Hp,
+                                                          double* __restrict__ st, StateLayout lay) {
+    // block b owns rows [32b, 32b+32) of SigmaA: the diagonal from the chunk partials, zeros elsewhere
+    // (SigmaA is diagonal here: write full rows so stale off-diagonals never survive)
+    __shared__ double diag[32];
+    if (threadIdx.x < 32) {
+        const int h = blockIdx.x * 32 + threadIdx.x;
+        double s = 0.0;
+        for (int q = 0; q < COLSUM_CHUNKS; ++q) s += part[(long long)q * Hp + h];
+        diag[threadIdx.x] = h < H ? s : 0.0;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 32 * Hp; t += blockDim.x) {
+        const int r = t / Hp, j = t - r * Hp, h = blockIdx.x * 32 + r;
+        st[lay.SA() + (long long)h * Hp + j] = (j == h) ? diag[r] : 0.0;
     }
 }
 
@@ -174,7 +203,7 @@ __global__ __launch_bounds__(T * T) void sparse_cov_b_kernel(double* __restrict_
 }
 
 // flags: bit1 est_cb -> CB/delta, bit2 sigma update, bit3 d + loop bookkeeping, bit4 tr(B'Q) from the identity
-__global__ __launch_bounds__(256) void sparse_ctrl_end_kernel(double* __restrict__ st, StateLayout lay, int H,
+__global__ __launch_bounds__(1024) void sparse_ctrl_end_kernel(double* __restrict__ st, StateLayout lay, int H,
                                                               double Lg, int flags, double eps,
                                                               double* __restrict__ trace, int* __restrict__ ints) {
     __shared__ double red[16];

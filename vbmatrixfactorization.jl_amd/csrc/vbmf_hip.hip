@@ -90,6 +90,8 @@ struct vbmf_ctx {
     double prof_n[2] = {0, 0};
     ncclComm_t comm = nullptr;
     bool comm_ready = false;
+    vbmf_allreduce_fn ar_hook = nullptr;   // bring-up transport instead of RCCL (vbmf_comm_set_transport)
+    void* ar_user = nullptr;
     int lds_limit = 65536;
 };
 
@@ -264,6 +266,17 @@ static int launch_stream(vbmf_ctx* c, int pass, int ctrl_mode = 0) {
     return VBMF_OK;
 }
 
+// sum all-reduce of a device buffer over the ranks, in place, ordered on the context's stream
+static int allreduce_sum(vbmf_ctx* c, void* buf, size_t count, bool is_double) {
+    if (c->ar_hook) {
+        const int rc = c->ar_hook(c->ar_user, buf, count, is_double ? 1 : 0, (void*)c->stream);
+        if (rc != 0) FAIL(c, VBMF_ERR_COMM, "all-reduce transport hook failed (%d)", rc);
+        return VBMF_OK;
+    }
+    NCCLCHK(c, ncclAllReduce(buf, buf, count, is_double ? ncclDouble : ncclFloat, ncclSum, c->comm, c->stream));
+    return VBMF_OK;
+}
+
 static int launch_post(vbmf_ctx* c, int which, const float* In, int nslab) {
     const Dims& d = which == 0 ? c->d1 : c->d2;
     const long long ld = (long long)d.XT * 32;
@@ -310,7 +323,7 @@ static int launch_post_gram(vbmf_ctx* c, int which, const float* In, int nslab) 
     HIPCHK(c, hipGetLastError());
     if (shard) {
         if (!c->comm_ready) FAIL(c, VBMF_ERR_COMM, "nranks > 1 but vbmf_comm_init was not called");
-        NCCLCHK(c, ncclAllReduce(c->gtmp, c->gtmp, 2 * (size_t)n, ncclDouble, ncclSum, c->comm, c->stream));
+        TRY(allreduce_sum(c, c->gtmp, 2 * (size_t)n, true));
         hipLaunchKernelGGL(gated_copy_kernel, dim3((2 * n + 255) / 256), dim3(256), 0, c->stream, c->gtmp,
                            c->st + c->lay.GB(), 2 * n, stop);
         HIPCHK(c, hipGetLastError());
@@ -349,7 +362,7 @@ static int launch_gram(vbmf_ctx* c, int which, const float* cur, const float* pr
     HIPCHK(c, hipGetLastError());
     if (shard) {
         if (!c->comm_ready) FAIL(c, VBMF_ERR_COMM, "nranks > 1 but vbmf_comm_init was not called");
-        NCCLCHK(c, ncclAllReduce(c->gtmp, c->gtmp, 2 * (size_t)n, ncclDouble, ncclSum, c->comm, c->stream));
+        TRY(allreduce_sum(c, c->gtmp, 2 * (size_t)n, true));
         // gated copy into the state (after `stop` the state must stay frozen)
         hipLaunchKernelGGL(gated_copy_kernel, dim3((2 * n + 255) / 256), dim3(256), 0, c->stream, c->gtmp,
                            c->st + c->lay.GB(), 2 * n, stop);
@@ -407,7 +420,7 @@ static int launch_eig(vbmf_ctx* c, int do_d, int do_b) {
 }
 
 static int launch_ctrl_end(vbmf_ctx* c, int flags, double eps, double* trace) {
-    hipLaunchKernelGGL(ctrl_end_kernel, dim3(1), dim3(256), 0, ctrl_stream(c), c->st, c->lay, (int)c->H, (double)c->Lg,
+    hipLaunchKernelGGL(ctrl_end_kernel, dim3(1), dim3(c->H > 128 ? 1024 : 256), 0, ctrl_stream(c), c->st, c->lay, (int)c->H, (double)c->Lg,
                        (double)c->M, flags, eps, trace, c->ints);
     HIPCHK(c, hipGetLastError());
     return VBMF_OK;
@@ -421,7 +434,7 @@ static int ensure_ready(vbmf_ctx* c) {
         double* dst = c->st + c->lay.scal() + S_TRYY;
         HIPCHK(c, hipMemcpyAsync(dst, &c->trYY_local, sizeof(double), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        NCCLCHK(c, ncclAllReduce(dst, dst, 1, ncclDouble, ncclSum, c->comm, c->stream));
+        TRY(allreduce_sum(c, dst, 1, true));
         c->trYY_reduced = true;
     }
     return VBMF_OK;
@@ -459,7 +472,7 @@ static int do_update_A(vbmf_ctx* c) {
                            c->Pred, n, c->ints + I_STOP);
         HIPCHK(c, hipGetLastError());
         if (sharded(c))
-            NCCLCHK(c, ncclAllReduce(c->Pred, c->Pred, (size_t)n, ncclFloat, ncclSum, c->comm, c->stream));
+            TRY(allreduce_sum(c, c->Pred, (size_t)n, false));
         if (fused_gram(c)) TRY(launch_post_gram(c, 0, c->Pred, 1));
         else TRY(launch_post(c, 0, c->Pred, 1));
     } else {
@@ -510,7 +523,7 @@ static int prepare_trYBA(vbmf_ctx* c, int* flag) {
         const long long ld = (long long)c->d2.XT * 32;
         hipLaunchKernelGGL(dot_kernel, dim3(grid_for(c->L, 256, 1024)), dim3(256), 0, c->stream, c->Q, ld, c->d2.nsplit,
                            (long long)c->Hp * ld, c->B32[c->bcur], c->Hp, (long long)c->L, dst);
-        if (sharded(c)) NCCLCHK(c, ncclAllReduce(dst, dst, 1, ncclDouble, ncclSum, c->comm, c->stream));
+        if (sharded(c)) TRY(allreduce_sum(c, dst, 1, true));
     }
     HIPCHK(c, hipGetLastError());
     *flag = 0;
@@ -1091,6 +1104,17 @@ int vbmf_comm_init(vbmf_ctx* c, const void* id128) {
     return VBMF_OK;
 }
 
+int vbmf_comm_set_transport(vbmf_ctx* c, vbmf_allreduce_fn fn, void* user) {
+    if (!c || !fn) return VBMF_ERR_INVALID;
+    if (c->comm_ready) FAIL(c, VBMF_ERR_INVALID, "communicator already initialised");
+    c->ar_hook = fn;
+    c->ar_user = user;
+    c->comm_ready = true;
+    c->trYY_reduced = false;
+    c->gA_valid = c->gB_valid = false;
+    return VBMF_OK;
+}
+
 // ---- measurement -------------------------------------------------------------------------------
 int vbmf_profile_enable(vbmf_ctx* c, int on) {
     if (!c) return VBMF_ERR_INVALID;
@@ -1212,7 +1236,9 @@ static int launch_sparse_cov_b(vbmf_ctx* c) {
 }
 
 static int sparse_colsum(vbmf_ctx* c) {
-    hipLaunchKernelGGL(colsum_kernel, dim3(c->Hp / 32), dim3(256), 0, c->stream, c->dS32, (long long)c->M, (int)c->H, c->Hp, c->st, c->lay);
+    double* part = c->st + c->lay.W1();      // scratch: COLSUM_CHUNKS * Hp <= Hp * Hp doubles (Hp >= 32)
+    hipLaunchKernelGGL(colsum_part_kernel, dim3(c->Hp / 32, COLSUM_CHUNKS), dim3(256), 0, c->stream, c->dS32, (long long)c->M, (int)c->H, c->Hp, part);
+    hipLaunchKernelGGL(colsum_fold_kernel, dim3(c->Hp / 32), dim3(256), 0, c->stream, part, (int)c->H, c->Hp, c->st, c->lay);
     HIPCHK(c, hipGetLastError());
     return VBMF_OK;
 }
@@ -1263,7 +1289,7 @@ static int sparse_update_CA(vbmf_ctx* c) {
 }
 
 static int launch_sparse_ctrl_end(vbmf_ctx* c, int flags, double eps, double* trace) {
-    hipLaunchKernelGGL(sparse_ctrl_end_kernel, dim3(1), dim3(256), 0, c->stream, c->st, c->lay, (int)c->H, (double)c->Lg, flags, eps, trace, c->ints);
+    hipLaunchKernelGGL(sparse_ctrl_end_kernel, dim3(1), dim3(c->H > 64 ? 1024 : 256), 0, c->stream, c->st, c->lay, (int)c->H, (double)c->Lg, flags, eps, trace, c->ints);
     HIPCHK(c, hipGetLastError());
     return VBMF_OK;
 }

@@ -26,3 +26,27 @@ def init_comm(ctx, rank, world, broadcast_bytes):
     uid = capi.Context.unique_id() if rank == 0 else None
     uid = broadcast_bytes(uid)
     ctx.comm_init(uid)
+
+
+def host_staged_transport(all_reduce_numpy):
+    """All-reduce transport that stages through host memory: for bring-up and for tests that run several ranks
+    on ONE GPU (RCCL refuses two ranks on a device).  `all_reduce_numpy(a)` must sum the 1-D numpy array `a`
+    over the ranks in place (e.g. a gloo torch.distributed.all_reduce on torch.from_numpy(a)).  Returns a
+    function for Context.comm_set_transport."""
+    import ctypes as C
+    import numpy as np
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+
+    def fn(buf, count, is_double, stream):
+        a = np.empty(count, dtype=np.float64 if is_double else np.float32)
+        if hip.hipStreamSynchronize(stream) != 0:
+            return 2
+        if hip.hipMemcpy(a.ctypes.data, buf, a.nbytes, 2) != 0:          # hipMemcpyDeviceToHost
+            return 3
+        all_reduce_numpy(a)
+        if hip.hipMemcpy(buf, a.ctypes.data, a.nbytes, 1) != 0:          # hipMemcpyHostToDevice
+            return 4
+        return 0
+    return fn
