@@ -1,5 +1,5 @@
 // bigh_tune.hip -- developer harness for the H >= 128 shapes (NH = 4, 8) of the streaming contraction.
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I vbmatrixfactorization.jl_amd/csrc scripts/bigh_tune.hip -o scripts/bigh_tune.bin
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I vbmatrixfactorization.jl_amd/csrc -I scripts scripts/bigh_tune.hip -o scripts/bigh_tune.bin
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -7,6 +7,7 @@
 #include <algorithm>
 #include "common.hpp"
 #include "stream_gemm.hpp"
+#include "experiments/stream_gemm_lds.hpp"
 using namespace vbmf;
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
@@ -41,7 +42,7 @@ static double time_ms(F&& launch, int iters) {
 
 struct Shape { long long X, K; int H; const char* name; };
 
-template <int NH, int NXW, int DY, int DF>
+template <int NH, int NXW, int DY, int DF, int FDBG = 0>
 static void run_variant(const Shape& sh, const uint4* Y, const uint4* F, float* O, size_t obytes, const char* tag) {
     const int XT = (int)(((sh.X + 31) / 32 + NXW - 1) / NXW * NXW);
     const int XG = XT / NXW, bps = (XG + 3) / 4;
@@ -58,7 +59,7 @@ static void run_variant(const Shape& sh, const uint4* Y, const uint4* F, float* 
         const int KS = sps * ns;
         if ((size_t)ns * NH * 32 * ld * 4 > obytes) continue;
         const double yb = (double)sh.X * sh.K * 2.0;
-        double ms = time_ms([&] { hipLaunchKernelGGL((stream_gemm_kernel<2, NH, NXW, DY, DF, 0>), dim3(blocks), dim3(256), 0, 0, Y, F, O, XG, KS, sps, ns, ld, (const int*)nullptr, ca, 0); }, 5);
+        double ms = time_ms([&] { hipLaunchKernelGGL((stream_gemm_kernel<2, NH, NXW, DY, DF, 0, FDBG>), dim3(blocks), dim3(256), 0, 0, Y, F, O, XG, KS, sps, ns, ld, (const int*)nullptr, ca, 0); }, 5);
                 printf("  %-28s ns=%2d blocks=%3d: %.3f ms  %.0f GB/s (Y only)\n", tag, ns, blocks, ms, yb / ms / 1e6);
         if (ms < best) { best = ms; bestns = ns; }
         if (false) {
@@ -71,6 +72,39 @@ static void run_variant(const Shape& sh, const uint4* Y, const uint4* F, float* 
         }
     }
     printf("  => %s best %.3f ms at ns=%d\n", tag, best, bestns);
+}
+
+__global__ void k_diff(const float* a, const float* b, size_t n, unsigned long long* cnt) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long c = 0;
+    for (; i < n; i += (size_t)gridDim.x * blockDim.x) c += (__float_as_uint(a[i]) != __float_as_uint(b[i]));
+    if (c) atomicAdd(cnt, c);
+}
+
+// LDS-shared-factor kernel vs the per-wave kernel at the same decomposition: time + bitwise comparison
+template <int NH, int NXW, int DY, int DF, int DYL, int GF>
+static void run_lds(const Shape& sh, const uint4* Y, const uint4* F, float* O, size_t obytes, int ns, const char* tag) {
+    const int XT = (int)(((sh.X + 31) / 32 + NXW - 1) / NXW * NXW);
+    const int XG = XT / NXW, bps = (XG + 3) / 4;
+    const int KS0 = (int)((sh.K + 15) / 16);
+    const long long ld = (long long)XT * 32;
+    CtrlArgs ca{}; ca.mode = 0;
+    int sps = (KS0 + ns - 1) / ns; sps = (sps + 11) / 12 * 12;
+    const int KS = sps * ns, blocks = bps * ns;
+    const size_t n = (size_t)ns * NH * 32 * ld;
+    if (2 * n * 4 > obytes) { printf("  (output too large)\n"); return; }
+    float* O2 = O + n;
+    const size_t lds = (size_t)LDS_STAGES * 2 * NH * 1024;
+    CK(hipFuncSetAttribute((const void*)stream_gemm_lds_kernel<2, NH, NXW, DYL, GF, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const double yb = (double)sh.X * sh.K * 2.0;
+    CK(hipMemset(O, 0xff, n * 4)); CK(hipMemset(O2, 0xee, n * 4));
+    double t0 = time_ms([&] { hipLaunchKernelGGL((stream_gemm_kernel<2, NH, NXW, DY, DF, 0>), dim3(blocks), dim3(256), 0, 0, Y, F, O, XG, KS, sps, ns, ld, (const int*)nullptr, ca, 0); }, 5);
+    double t1 = time_ms([&] { hipLaunchKernelGGL((stream_gemm_lds_kernel<2, NH, NXW, DYL, GF, 0>), dim3(blocks), dim3(256), lds, 0, Y, F, O2, XG, KS, sps, ns, ld, (const int*)nullptr, ca, 0); }, 5);
+    unsigned long long* cnt; CK(hipMalloc(&cnt, 8)); CK(hipMemset(cnt, 0, 8));
+    hipLaunchKernelGGL(k_diff, dim3(1024), dim3(256), 0, 0, O, O2, n, cnt);
+    unsigned long long h = 0; CK(hipMemcpy(&h, cnt, 8, hipMemcpyDeviceToHost)); CK(hipFree(cnt));
+    printf("  %-22s ns=%2d blocks=%3d: per-wave %.3f ms (%.0f GB/s)   LDS-shared %.3f ms (%.0f GB/s)   differing words: %llu of %zu\n",
+           tag, ns, blocks, t0, yb / t0 / 1e6, t1, yb / t1 / 1e6, h, n);
 }
 
 int main(int argc, char** argv) {
@@ -90,14 +124,21 @@ int main(int argc, char** argv) {
         const Shape& sh = shapes[si];
         printf("== %s\n", sh.name);
         if (sh.H == 256) {
-            run_variant<8, 2, 4, 1>(sh, Y, F, O, obytes, "NH8 NXW2 DY4 DF1 fine");
-            run_variant<8, 2, 4, 2>(sh, Y, F, O, obytes, "NH8 NXW2 DY4 DF2 fine");
-            run_variant<8, 2, 2, 2>(sh, Y, F, O, obytes, "NH8 NXW2 DY2 DF2 fine");
-            run_variant<8, 2, 6, 3>(sh, Y, F, O, obytes, "NH8 NXW2 DY6 DF3 fine");
+            run_lds<8, 2, 2, 2, 3, 1>(sh, Y, F, O, obytes, si == 0 ? 6 : 1, "NH8 NXW2 lds DY3 GF1");
+            run_lds<8, 2, 2, 2, 4, 2>(sh, Y, F, O, obytes, si == 0 ? 6 : 1, "NH8 NXW2 lds DY4 GF2");
+            run_lds<8, 2, 2, 2, 6, 2>(sh, Y, F, O, obytes, si == 0 ? 6 : 1, "NH8 NXW2 lds DY6 GF2");
+            continue;
+            run_variant<8, 2, 2, 2>(sh, Y, F, O, obytes, "NH8 NXW2 DY2 DF2");
+            run_variant<8, 2, 2, 2, 1>(sh, Y, F, O, obytes, "NH8 NXW2 DY2 DF2 F L1-hot");
+            run_variant<8, 2, 2, 2, 2>(sh, Y, F, O, obytes, "NH8 NXW2 DY2 DF2 no F loads");
         } else {
-            run_variant<4, 4, 4, 2>(sh, Y, F, O, obytes, "NH4 NXW4 DY4 DF2 fine");
-            run_variant<4, 4, 6, 3>(sh, Y, F, O, obytes, "NH4 NXW4 DY6 DF3 fine");
-            run_variant<4, 4, 4, 4>(sh, Y, F, O, obytes, "NH4 NXW4 DY4 DF4 fine");
+            run_lds<4, 4, 4, 2, 4, 2>(sh, Y, F, O, obytes, si == 2 ? 12 : 1, "NH4 NXW4 lds DY4 GF2");
+            run_lds<4, 4, 4, 2, 3, 1>(sh, Y, F, O, obytes, si == 2 ? 12 : 1, "NH4 NXW4 lds DY3 GF1");
+            run_lds<4, 4, 4, 2, 6, 3>(sh, Y, F, O, obytes, si == 2 ? 12 : 1, "NH4 NXW4 lds DY6 GF3");
+            continue;
+            run_variant<4, 4, 4, 2>(sh, Y, F, O, obytes, "NH4 NXW4 DY4 DF2");
+            run_variant<4, 4, 4, 2, 1>(sh, Y, F, O, obytes, "NH4 NXW4 DY4 DF2 F L1-hot");
+            run_variant<4, 4, 4, 2, 2>(sh, Y, F, O, obytes, "NH4 NXW4 DY4 DF2 no F loads");
         }
     }
     return 0;

@@ -42,7 +42,8 @@ namespace vbmf {
 // cache policy of the Y stream: 2 = nt (streamed once); 0 = default
 constexpr int Y_AUX = 2;
 
-template <int MODE, int NH, int NXW_, int DY, int DF, int RCTRL>
+// FDBG (tuning harness only): 1 = the factor ring re-reads one L1-hot k-step, 2 = no factor refills at all
+template <int MODE, int NH, int NXW_, int DY, int DF, int RCTRL, int FDBG = 0>
 __global__ __launch_bounds__(256) void stream_gemm_kernel(const uint4* __restrict__ Yt,   // [XT][KS][64]
                                                           const uint4* __restrict__ Ft,   // [KS][NPART][NH][64]
                                                           float* __restrict__ Out,        // [nsplit][NH*32][ldOut]
@@ -144,9 +145,10 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const uint4* __restric
                             acc[i][j % NH] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                                 fa, __builtin_bit_cast(bf16x8, yb[d][i]), acc[i][j % NH], 0, 0, 0);
                     }
-                    fb[fd][j] = __builtin_amdgcn_raw_buffer_load_b128(fr, voff, ((s + d + DF) * NF + j) * 1024, 0);
+                    if constexpr (FDBG != 2)
+                        fb[fd][j] = __builtin_amdgcn_raw_buffer_load_b128(fr, voff, ((FDBG == 1 ? d : s + d + DF) * NF + j) * 1024, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, NXW_ * (MODE == MODE_F32 ? 4 : 1), 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    if constexpr (FDBG != 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 }
 #pragma unroll
                 for (int i = 0; i < NXW_; ++i)
