@@ -111,6 +111,11 @@ int vbmf_get_state(vbmf_ctx* ctx, double* AHat, int64_t ldA, double* BHat, int64
  * (src/vbmf.jl:194-204).  For callers that drive the updates themselves (examples/mil_util.jl:183-185). */
 int vbmf_step(vbmf_ctx* ctx, int which);
 
+/* Fixed-basis inference, the reference's main caller of the update functions outside vbmf! -- vbls!
+ * (examples/mil_util.jl:179-203, vbmf_parameters branch): niter x (updateA!, updateCA!, updateSigma2!) with BHat,
+ * SigmaB, CB frozen.  B is fixed, so Y'B is formed once: ONE pass over Y per call instead of two per iteration. */
+int vbmf_run_fixed_basis(vbmf_ctx* ctx, int64_t niter);
+
 /* The vbmf! loop (src/vbmf.jl:187-214): while i <= niter && d > eps { A; B; [CA; CB]; [sigma2]; d }.
  * Runs entirely on the device; the stop test is evaluated device-side so the state freezes exactly
  * where the reference would stop.  iters_done = i-1 (src/vbmf.jl:221), d_last = last d.
@@ -146,6 +151,8 @@ int vbmf_sparse_set_state(vbmf_ctx* ctx, const double* ATVecHat, const double* d
 int vbmf_sparse_get_state(vbmf_ctx* ctx, double* ATVecHat, double* diagSigmaATVec, double* CA, double* beta,
                           double* SigmaA_diag, double* BHat, int64_t ldB, double* SigmaB, double* CB,
                           double* delta, double* sigmaHat, double* zeta);
+/* vbls! on the sparse model (examples/mil_util.jl:187-190): niter x (updateA!, updateCA!, updateSigma!), B frozen */
+int vbmf_sparse_run_fixed_basis(vbmf_ctx* ctx, int64_t niter);
 int vbmf_sparse_step(vbmf_ctx* ctx, int which);            /* reference order A, B, CA, CB, SIGMA (:369-376) */
 /* vbmf_sparse! loop (src/vbmf_sparse.jl:344-410): returns d like the reference; trace: niter x 4 (d, sigmaHat, 0, 0) */
 int vbmf_sparse_run(vbmf_ctx* ctx, int64_t niter, double eps, int est_cb, int64_t* iters_done, double* d_last,

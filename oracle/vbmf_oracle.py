@@ -265,6 +265,29 @@ def vbls_(Y, p, niter):
     return p.AHat
 
 
+def copy_vbmf_params(Y, old, rng=None):
+    """examples/mil_util.jl:212-236: fresh parameters for a new Y keeping BHat, SigmaB, CB, invCB [, gamma, delta]."""
+    if isinstance(old, vbmf_parameters):
+        p = vbmf_init(Y, old.H, sigma2=old.sigma2, rng=rng, materialize_yhat=False)
+        p.BHat, p.SigmaB = old.BHat.copy(), old.SigmaB.copy()
+        p.CB, p.invCB = old.CB.copy(), old.invCB.copy()
+        return p
+    p = vbmf_sparse_init(Y, old.H, alpha0=old.alpha0, beta0=old.beta0, gamma0=old.gamma0, delta0=old.delta0,
+                         eta0=old.eta0, zeta0=old.zeta0, rng=rng, full_cov=False, materialize_yhat=False)
+    p.BHat, p.SigmaB, p.CB = old.BHat.copy(), old.SigmaB.copy(), old.CB.copy()
+    p.gamma, p.delta = old.gamma, old.delta.copy()
+    return p
+
+
+def vbls_sparse_(Y, p, niter, reference_compat=True):
+    """examples/mil_util.jl:187-190, vbmf_sparse_parameters branch (full_cov=false, diag_var=false)."""
+    for _ in range(niter):
+        sparse_updateA(Y, p, full_cov=False, reference_compat=reference_compat)
+        sparse_updateCA(p)
+        sparse_updateSigma(Y, p)
+    return p.AHat
+
+
 # ----------------------------------------------------------------------------------------------
 # ARD-sparse VBMF  (src/vbmf_sparse.jl), diag_var=false only
 # ----------------------------------------------------------------------------------------------

@@ -34,11 +34,11 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _spawn(world, transport, outdir):
+def _spawn(world, transport, outdir, case):
     port = _free_port()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "two_rank_worker.py"), str(r), str(world),
-                               str(port), str(outdir), transport], env=env, cwd=ROOT) for r in range(world)]
+                               str(port), str(outdir), transport, case], env=env, cwd=ROOT) for r in range(world)]
     try:
         rcs = [p.wait(timeout=240) for p in procs]
     finally:
@@ -49,19 +49,19 @@ def _spawn(world, transport, outdir):
     return [dict(np.load(os.path.join(outdir, f"rank{r}.npz"))) for r in range(world)]
 
 
-def _check(pkg, world, transport, tmp_path):
-    L, M, H = W.SHAPE
+def _check(pkg, world, transport, tmp_path, case="h12"):
+    L, M, H = W.CASES[case]
     Y, A0, B0 = W.problem(L, M, H, W.SEED)
     with pkg.capi.Context(L, M, H, y_dtype=pkg.VBMF_Y_BF16) as c:
-        ref = W.run(pkg, c, Y, A0, B0, H)
-    ranks = _spawn(world, transport, tmp_path)
+        ref = W.run(pkg, c, Y, A0, B0, H, W.NITERS[case])
+    ranks = _spawn(world, transport, tmp_path, case)
     # replicated quantities are bit-identical across the ranks (they see the same reduced sums)
     for k in ("AHat", "SigmaA", "SigmaB", "CA_diag", "CB_diag", "sigma2", "d", "trace", "trYY", "it"):
         for r in ranks[1:]:
             assert np.array_equal(ranks[0][k], r[k]), k
     B = np.concatenate([r["BHat"] for r in ranks], axis=0)
     assert [int(r["row0"]) for r in ranks] == [pkg.dist.row_shard(L, world, i)[0] for i in range(world)]
-    assert B.shape == (L, H) and int(ranks[0]["it"]) == ref["it"] == W.NITER
+    assert B.shape == (L, H) and int(ranks[0]["it"]) == ref["it"] == W.NITERS[case]
     errs = dict(A=relF(ranks[0]["AHat"], ref["AHat"]), B=relF(B, ref["BHat"]),
                 SA=relF(ranks[0]["SigmaA"], ref["SigmaA"]), SB=relF(ranks[0]["SigmaB"], ref["SigmaB"]),
                 ca=relF(ranks[0]["CA_diag"], ref["CA_diag"]), cb=relF(ranks[0]["CB_diag"], ref["CB_diag"]),
@@ -69,7 +69,7 @@ def _check(pkg, world, transport, tmp_path):
                 trYY=abs(float(ranks[0]["trYY"]) - ref["trYY"]) / ref["trYY"],
                 d=abs(float(ranks[0]["d"]) - ref["d"]) / ref["d"],
                 elbo=abs(float(ranks[0]["elbo"]) - ref["elbo"]) / abs(ref["elbo"]))
-    report(f"{world} ranks ({transport} transport) vs 1 rank, {L}x{M} H={H}, {W.NITER} sweeps: "
+    report(f"{world} ranks ({transport} transport) vs 1 rank, {L}x{M} H={H}, {W.NITERS[case]} sweeps: "
            + " ".join(f"{k}={v:.2e}" for k, v in errs.items()))
     # same arithmetic, different summation order of the row partials (fp32 partial sums of Y'B, fp64 Grams).
     # sigma2 is the reference's cancelling difference ||Y||^2 - 2tr + tr (x ~400 here), and SigmaA/SigmaB scale
@@ -86,6 +86,11 @@ def test_two_ranks_one_gpu_host_transport(pkg, tmp_path):
 
 def test_three_ranks_one_gpu_host_transport(pkg, tmp_path):
     _check(pkg, 3, "host", tmp_path)
+
+
+@pytest.mark.parametrize("case", ["h128", "h200"])
+def test_two_ranks_large_rank_paths(pkg, tmp_path, case):
+    _check(pkg, 2, "host", tmp_path, case)
 
 
 def test_two_gpus_rccl(pkg, tmp_path):

@@ -1,0 +1,69 @@
+"""Fixed-basis inference: vbls! + copy_vbmf_params of examples/mil_util.jl:179-236 --
+the device loop (vbmf_run_fixed_basis / vbmf_sparse_run_fixed_basis: Y'B formed once, B frozen) against the oracle's
+restatement, which repeats the reference's full updates.  PARITY UNPINNED (no recorded vbls! run in the reference)."""
+import numpy as np
+import pytest
+
+import __graft_entry__ as G
+from oracle import vbmf_oracle as O
+from tests.helpers import compare, relF, report, to_pkg_params
+from tests.test_gpu_sparse import _cmp, _to_pkg
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    G.build()
+    return G.load_package()
+
+
+def _train_and_new_bag(L, M, M2, H, seed):
+    """A factorization trained on Y (L x M), then a NEW matrix with the same row space and another M (a 'bag')."""
+    rng = np.random.default_rng(seed)
+    Bs = rng.standard_normal((L, H)) * np.linspace(1.0, 2.5, H)
+    def draw(m):
+        As = np.zeros((m, H)); As[np.arange(m), rng.integers(0, H, m)] = 1.0
+        return Bs @ As.T + 0.05 * rng.standard_normal((L, m))
+    return draw(M), draw(M2)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x2"])
+def test_vbls_basic_device_loop(pkg, mode):
+    L, M, M2, H = 500, 300, 177, 6
+    Y, Y2 = _train_and_new_bag(L, M, M2, H, 77)
+    ydt = pkg.VBMF_Y_F32 if mode == "f32" else pkg.VBMF_Y_BF16
+    pkg.set_defaults(y_dtype=ydt, factor_dtype=pkg.VBMF_FACTOR_AUTO)
+    with pkg.capi.Context(L, M2, H, y_dtype=ydt) as c:       # the bag exactly as the device stores it
+        c.set_Y(Y2)
+        Y2s = np.ascontiguousarray(c.get_Y())
+    po = O.vbmf_init(Y, H, ca=0.1, cb=0.1, sigma2=0.1, rng=np.random.default_rng(5), materialize_yhat=False)
+    O.vbmf_(Y, po, 30, eps=0.0, est_covs=True, est_var=True)
+    qo = O.copy_vbmf_params(Y2s, po, rng=np.random.default_rng(6))
+    qg = pkg.copy_vbmf_params(Y2s, to_pkg_params(pkg, po), rng=np.random.default_rng(6))
+    assert np.array_equal(qg.AHat, qo.AHat) and np.array_equal(qg.BHat, po.BHat) and qg.M == M2
+    A_gpu = pkg.vbls_(Y2s, qg, 20)
+    O.vbls_(Y2s, qo, 20)
+    # B round-trips through the device's factor storage (fp32; hi+lo bf16 = 2^-17 relative in the bf16 modes)
+    assert A_gpu is qg.AHat and relF(qg.BHat, po.BHat) < 1e-5
+    tol = dict(default=2e-4, sigma2=2e-3) if mode == "f32" else dict(default=4e-4, sigma2=4e-3)
+    compare(f"vbls! device loop, 20 iterations, {mode}", qg, qo, tol, fields=("AHat", "SigmaA", "CA"))
+    assert relF(qg.YHat, qo.BHat @ qo.AHat.T) < 1e-3
+
+
+def test_vbls_sparse_device_loop(pkg):
+    L, M, M2, H = 400, 260, 150, 5
+    Y, Y2 = _train_and_new_bag(L, M, M2, H, 91)
+    pkg.set_defaults(y_dtype=pkg.VBMF_Y_F32, factor_dtype=pkg.VBMF_FACTOR_AUTO)
+    Y2s = Y2.astype(np.float32).astype(np.float64)
+    po = O.vbmf_sparse_init(Y, H, ca=1.0, cb=1.0, sigma=1.0, rng=np.random.default_rng(7), full_cov=False,
+                            materialize_yhat=False)
+    O.vbmf_sparse_(Y, po, 12, eps=0.0, full_cov=False)
+    qo = O.copy_vbmf_params(Y2s, po, rng=np.random.default_rng(8))
+    qg = pkg.copy_vbmf_params(Y2s, _to_pkg(pkg, po), rng=np.random.default_rng(8))
+    assert np.array_equal(qg.ATVecHat, qo.ATVecHat) and qg.gamma == po.gamma
+    pkg.vbls_(Y2s, qg, 10)
+    O.vbls_sparse_(Y2s, qo, 10)
+    _cmp("vbls! sparse device loop, 10 iterations", qg, qo, 2e-3,
+         fields=("ATVecHat", "diagSigmaATVec", "SigmaA", "CA", "beta"))
+    assert relF(qg.BHat, po.BHat) < 1e-6

@@ -1,6 +1,6 @@
 """Worker of tests/test_gpu_two_ranks.py: one rank of a row-sharded run (one process per rank).
 
-    python tests/two_rank_worker.py RANK WORLD PORT OUTDIR TRANSPORT
+    python tests/two_rank_worker.py RANK WORLD PORT OUTDIR TRANSPORT CASE
 
 TRANSPORT = "host": the library's all-reduces go through vbmf_comm_set_transport + a gloo all-reduce on host
 copies, so that several ranks can share ONE GPU; "rccl": the real communicator, one GPU per rank."""
@@ -13,36 +13,41 @@ import numpy as np
 def problem(L, M, H, seed):
     """Common to all ranks and to the single-context reference run in the parent (seeded)."""
     rng = np.random.default_rng(seed)
-    Bs = rng.standard_normal((L, H)) * np.linspace(1.0, 3.0, H)
-    As = np.zeros((M, H))
-    As[np.arange(M), rng.integers(0, H, M)] = 1.0
+    Hs = H                                  # latent rank = model rank, well separated scales: a well-conditioned fixed point
+    Bs = rng.standard_normal((L, Hs)) * np.linspace(1.0, 3.0, Hs)
+    As = np.zeros((M, Hs))
+    As[np.arange(M), rng.integers(0, Hs, M)] = 1.0
     Y = Bs @ As.T + 0.05 * rng.standard_normal((L, M))
     A0, B0 = rng.standard_normal((M, H)), rng.standard_normal((L, H))
     return Y, A0, B0
 
 
-SHAPE = (1531, 700, 12)        # L deliberately not a multiple of the rank count
-NITER, EPS, SEED = 12, 0.0, 4242
+# name -> (L, M, H): L deliberately not a multiple of the rank count.  "h128" runs the H = 128 kernels of the
+# 8-GPU BASELINE configuration (16 accumulator tiles per wave, un-fused post/Gram), "h200" the H > 128 control path.
+CASES = {"h12": (1531, 700, 12), "h128": (1203, 520, 128), "h200": (901, 420, 200)}
+EPS, SEED = 0.0, 4242
+NITERS = {"h12": 12, "h128": 5, "h200": 5}
 
 
-def run(pkg, ctx, Y, A0, B0, H):
+def run(pkg, ctx, Y, A0, B0, H, niter):
     z = np.zeros((H, H))
     ctx.set_Y(Y)
     ctx.set_state(A0, B0, z, z, 0.1 * np.ones(H), 0.1 * np.ones(H), 0.1)
-    it, d, tr = ctx.run(NITER, eps=EPS, est_covs=True, est_var=True, want_trace=True)
+    it, d, tr = ctx.run(niter, eps=EPS, est_covs=True, est_var=True, want_trace=True)
     s = ctx.get_state()
     return dict(it=it, d=d, trace=tr[:, :3], trYY=ctx.trYY(), elbo=ctx.elbo(), **s)
 
 
 def main():
     rank, world, port, outdir, transport = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+    case = sys.argv[6]
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import torch
     import torch.distributed as dist
     import __graft_entry__ as G
     pkg = G.load_package()
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
-    L, M, H = SHAPE
+    L, M, H = CASES[case]
     Y, A0, B0 = problem(L, M, H, SEED)
     r0, n = pkg.dist.row_shard(L, world, rank)
     dev = rank if transport == "rccl" else 0
@@ -54,7 +59,7 @@ def main():
             ctx.comm_init(uid[0])
         else:
             ctx.comm_set_transport(pkg.dist.host_staged_transport(lambda a: dist.all_reduce(torch.from_numpy(a))))
-        res = run(pkg, ctx, Y[r0:r0 + n], A0, B0[r0:r0 + n], H)
+        res = run(pkg, ctx, Y[r0:r0 + n], A0, B0[r0:r0 + n], H, NITERS[case])
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), row0=r0, nrows=n, **res)
     dist.barrier()
     dist.destroy_process_group()

@@ -451,3 +451,45 @@ def lowerBound(Y, params, clamp=True):
     c = _sparse_ctx(Y, params)
     _spush(c, params)
     return c.sparse_lower_bound(clamp=clamp)
+
+
+# =================================================================================================
+# Fixed-basis inference -- examples/mil_util.jl:179-236 (vbls!, copy_vbmf_params): the main caller of the
+# update functions outside vbmf!/vbmf_sparse! (150 resp. 20 iterations per bag in the MIL study,
+# examples/mil_util.jl:473-479,518-521)
+# =================================================================================================
+def vbls_(Y, params, niter, diag_var=False, full_cov=False):
+    """vbls! -- examples/mil_util.jl:179-203: solves Y = B A' + E for A with B (and SigmaB, CB) fixed: niter x
+    (updateA!, updateCA!, updateSigma2! / updateSigma!), then updateYHat!; returns params.AHat.
+    On the device Y'B is formed once per call (B is fixed), so the call reads Y once, not 2 x niter times."""
+    if full_cov or diag_var:
+        raise NotImplementedError("only full_cov=false, diag_var=false is built (SURVEY.md section 2)")
+    if isinstance(params, vbmf_sparse_parameters):
+        c = _sparse_ctx(Y, params)
+        _spush(c, params)
+        c.sparse_run_fixed_basis(int(niter))
+        _spull(c, params)
+        params.YHat = params.BHat @ params.AHat.T if params.L * params.M <= YHAT_AUTO_LIMIT else None
+        return params.AHat
+    _check(Y, params)
+    s = _session_for(Y, params.H)
+    s.push(params)
+    s.ctx.run_fixed_basis(int(niter))
+    s.pull(params)
+    params.YHat = s.ctx.YHat() if params.L * params.M <= YHAT_AUTO_LIMIT else None     # :201
+    return params.AHat
+
+
+def copy_vbmf_params(Y, old_params, rng=None):
+    """copy_vbmf_params -- examples/mil_util.jl:212-236: a fresh parameter set for a NEW Y (other M), keeping what
+    vbls! leaves fixed (BHat, SigmaB, CB, invCB [, gamma, delta]).  Labels and H1 are not carried over (:218)."""
+    if isinstance(old_params, vbmf_sparse_parameters):
+        p = vbmf_sparse_init(Y, old_params.H, alpha0=old_params.alpha0, beta0=old_params.beta0, gamma0=old_params.gamma0,
+                             delta0=old_params.delta0, eta0=old_params.eta0, zeta0=old_params.zeta0, rng=rng)
+        p.BHat, p.SigmaB, p.CB = old_params.BHat.copy(), old_params.SigmaB.copy(), old_params.CB.copy()
+        p.gamma, p.delta = old_params.gamma, old_params.delta.copy()
+        return p
+    p = vbmf_init(Y, old_params.H, sigma2=old_params.sigma2, rng=rng)
+    p.BHat, p.SigmaB = old_params.BHat.copy(), old_params.SigmaB.copy()
+    p.CB, p.invCB = old_params.CB.copy(), old_params.invCB.copy()
+    return p

@@ -21,10 +21,12 @@ UNIQUE_ID_BYTES = 128
 # every symbol include/vbmf_hip.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     "vbmf_default_opts", "vbmf_create", "vbmf_destroy", "vbmf_last_error", "vbmf_set_Y", "vbmf_set_Y_synthetic",
-    "vbmf_get_Y", "vbmf_get_trYY", "vbmf_set_state", "vbmf_get_state", "vbmf_step", "vbmf_run", "vbmf_get_YHat",
+    "vbmf_get_Y", "vbmf_get_trYY", "vbmf_set_state", "vbmf_get_state", "vbmf_step", "vbmf_run", "vbmf_run_fixed_basis",
+    "vbmf_get_YHat",
     "vbmf_elbo", "vbmf_comm_unique_id", "vbmf_comm_init", "vbmf_comm_set_transport", "vbmf_profile_enable", "vbmf_profile_read",
     "vbmf_pass_bytes", "vbmf_device_sync", "vbmf_debug_peek", "vbmf_debug_time_pass",
-    "vbmf_sparse_set_state", "vbmf_sparse_get_state", "vbmf_sparse_step", "vbmf_sparse_run", "vbmf_sparse_lower_bound",
+    "vbmf_sparse_set_state", "vbmf_sparse_get_state", "vbmf_sparse_step", "vbmf_sparse_run", "vbmf_sparse_run_fixed_basis",
+    "vbmf_sparse_lower_bound",
 ]
 SSTEP_A, SSTEP_B, SSTEP_CA, SSTEP_CB, SSTEP_SIGMA = 1, 2, 4, 8, 16
 PEEK_P, PEEK_Q, PEEK_A32, PEEK_B32, PEEK_FA, PEEK_FB, PEEK_Y1, PEEK_Y2, PEEK_DIMS = range(9)
@@ -90,6 +92,8 @@ def lib():
     L.vbmf_get_state.argtypes = [vp, dp, i64, dp, i64, dp, dp, dp, dp, dp]
     L.vbmf_step.argtypes = [vp, i32]
     L.vbmf_run.argtypes = [vp, i64, C.c_double, i32, i32, C.POINTER(i64), dp, dp]
+    L.vbmf_run_fixed_basis.argtypes = [vp, i64]
+    L.vbmf_sparse_run_fixed_basis.argtypes = [vp, i64]
     L.vbmf_get_YHat.argtypes = [vp, dp, i64]
     L.vbmf_elbo.argtypes = [vp, dp]
     L.vbmf_comm_unique_id.argtypes = [vp]
@@ -217,6 +221,12 @@ class Context:
         self._chk(self._lib.vbmf_run(self._h, niter, eps, int(est_covs), int(est_var), C.byref(it), C.byref(d),
                                      _dptr(tr)))
         return it.value, d.value, (tr[:it.value] if want_trace else None)
+
+    def run_fixed_basis(self, niter):
+        self._chk(self._lib.vbmf_run_fixed_basis(self._h, int(niter)))
+
+    def sparse_run_fixed_basis(self, niter):
+        self._chk(self._lib.vbmf_sparse_run_fixed_basis(self._h, int(niter)))
 
     def YHat(self):
         out = np.empty((self.L, self.M), order="F")

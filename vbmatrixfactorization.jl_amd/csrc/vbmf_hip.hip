@@ -457,9 +457,13 @@ static int ensure_gram_B(vbmf_ctx* c) {
 //   pass 1 of sweep i : [lambda_max + ctrl_end of sweep i-1] + SigmaA of sweep i
 //   pass 2 of sweep i : SigmaB of sweep i
 // Outside (vbmf_step, H > 128) the same device code runs as stand-alone kernels before the pass.
-static int do_update_A(vbmf_ctx* c) {
+// reuse_P: B has not changed since Y'B was last formed (fixed-basis inference, vbls!): skip the pass over Y
+static int do_update_A(vbmf_ctx* c, bool reuse_P = false) {
     TRY(ensure_gram_B(c));
-    if (fused_ctrl(c)) {
+    const bool have_P = reuse_P && c->P_valid;
+    if (have_P) {
+        TRY(launch_ctrl_cov(c, 0));
+    } else if (fused_ctrl(c)) {
         TRY(launch_stream(c, 0, CTRL_COV_A | (c->tail_pending ? CTRL_PREV_END : 0)));
         c->tail_pending = false;
     } else {
@@ -468,11 +472,13 @@ static int do_update_A(vbmf_ctx* c) {
     }
     if (sharded(c) || c->d1.nsplit > 1) {
         const long long n = (long long)c->Hp * c->d1.XT * 32;
-        hipLaunchKernelGGL(slab_sum_kernel, dim3(grid_for(n / 4, 256, 2048)), dim3(256), 0, c->stream, c->P, c->d1.nsplit, n,
-                           c->Pred, n, c->ints + I_STOP);
-        HIPCHK(c, hipGetLastError());
-        if (sharded(c))
-            TRY(allreduce_sum(c, c->Pred, (size_t)n, false));
+        if (!have_P) {
+            hipLaunchKernelGGL(slab_sum_kernel, dim3(grid_for(n / 4, 256, 2048)), dim3(256), 0, c->stream, c->P, c->d1.nsplit, n,
+                               c->Pred, n, c->ints + I_STOP);
+            HIPCHK(c, hipGetLastError());
+            if (sharded(c))
+                TRY(allreduce_sum(c, c->Pred, (size_t)n, false));
+        }
         if (fused_gram(c)) TRY(launch_post_gram(c, 0, c->Pred, 1));
         else TRY(launch_post(c, 0, c->Pred, 1));
     } else {
@@ -954,6 +960,26 @@ int vbmf_step(vbmf_ctx* c, int which) {
     return check_device_err(c);
 }
 
+// vbls! (examples/mil_util.jl:179-203), vbmf_parameters branch: niter x (updateA!, updateCA!, updateSigma2!) with
+// B, SigmaB, CB frozen.  B is fixed, so Y'B is formed ONCE (one pass over Y for the whole call, where the reference
+// reads Y twice per iteration) and tr(Y'BA') is the dot product of that M x H matrix with AHat.
+int vbmf_run_fixed_basis(vbmf_ctx* c, int64_t niter) {
+    if (!c) return VBMF_ERR_INVALID;
+    if (c->sparse) FAIL(c, VBMF_ERR_INVALID, "sparse context: use vbmf_sparse_run_fixed_basis");
+    if (niter < 0 || niter > (1ll << 30)) FAIL(c, VBMF_ERR_INVALID, "vbmf_run_fixed_basis: bad niter");
+    HIPCHK(c, hipSetDevice(c->o.device));
+    TRY(ensure_ready(c));
+    for (int64_t it = 0; it < niter; ++it) {
+        TRY(do_update_A(c, true));
+        TRY(ensure_gram_A(c));
+        int f = 0;
+        TRY(prepare_trYBA(c, &f));                          // P is current: the dot(P, A) branch
+        TRY(launch_ctrl_end(c, 1 | 4 | f, 0.0, nullptr));
+        if ((it & 63) == 63) TRY(check_device_err(c));      // bounds the launch queue
+    }
+    return check_device_err(c);
+}
+
 int vbmf_run(vbmf_ctx* c, int64_t niter, double eps, int est_covs, int est_var, int64_t* iters_done,
              double* d_last, double* trace) {
     if (!c) return VBMF_ERR_INVALID;
@@ -1243,12 +1269,14 @@ static int sparse_colsum(vbmf_ctx* c) {
     return VBMF_OK;
 }
 
-static int do_sparse_update_A(vbmf_ctx* c) {
+static int do_sparse_update_A(vbmf_ctx* c, bool reuse_P = false) {
     TRY(ensure_gram_B(c));
     hipLaunchKernelGGL(sparse_v_kernel, dim3((c->Hp + 63) / 64), dim3(64), 0, c->stream, c->st, c->lay, (int)c->H, (double)c->Lg, c->vtab);
-    TRY(launch_stream(c, 0));
-    const long long n = (long long)c->Hp * c->d1.XT * 32;
-    hipLaunchKernelGGL(slab_sum_kernel, dim3(grid_for(n / 4, 256, 2048)), dim3(256), 0, c->stream, c->P, c->d1.nsplit, n, c->Pred, n, c->ints + I_STOP);
+    if (!(reuse_P && c->P_valid)) {
+        TRY(launch_stream(c, 0));
+        const long long n = (long long)c->Hp * c->d1.XT * 32;
+        hipLaunchKernelGGL(slab_sum_kernel, dim3(grid_for(n / 4, 256, 2048)), dim3(256), 0, c->stream, c->P, c->d1.nsplit, n, c->Pred, n, c->ints + I_STOP);
+    }
     const int compat = (c->o.reference_compat & VBMF_COMPAT_SPARSE_REPEAT) ? 1 : 0;
     if (compat && c->M < 2) FAIL(c, VBMF_ERR_INVALID, "repeat(v, inner=M-1) needs M >= 2");
     hipLaunchKernelGGL(sparse_update_a_kernel, dim3(grid_for((int64_t)c->M * c->Hp)), dim3(256), 0, c->stream, c->Pred,
@@ -1422,6 +1450,25 @@ int vbmf_sparse_step(vbmf_ctx* c, int which) {
         flags |= 4 | f;
     }
     if (flags) TRY(launch_sparse_ctrl_end(c, flags, 0.0, nullptr));
+    return check_device_err(c);
+}
+
+// vbls!, vbmf_sparse_parameters branch (examples/mil_util.jl:187-190): updateA!, updateCA!, updateSigma! with B frozen
+int vbmf_sparse_run_fixed_basis(vbmf_ctx* c, int64_t niter) {
+    if (!c) return VBMF_ERR_INVALID;
+    if (!c->sparse) FAIL(c, VBMF_ERR_INVALID, "not a sparse context");
+    if (niter < 0 || niter > (1ll << 30)) FAIL(c, VBMF_ERR_INVALID, "bad niter");
+    HIPCHK(c, hipSetDevice(c->o.device));
+    TRY(ensure_ready(c));
+    for (int64_t it = 0; it < niter; ++it) {
+        TRY(do_sparse_update_A(c, true));
+        TRY(sparse_update_CA(c));
+        TRY(ensure_gram_A(c));
+        int f = 0;
+        TRY(prepare_trYBA(c, &f));
+        TRY(launch_sparse_ctrl_end(c, 4 | f, 0.0, nullptr));
+        if ((it & 63) == 63) TRY(check_device_err(c));
+    }
     return check_device_err(c);
 }
 
