@@ -161,6 +161,19 @@ int vbmf_sparse_run(vbmf_ctx* ctx, int64_t niter, double eps, int est_cb, int64_
  * normalEntropy's det (src/util.jl:118-122) when clamp != 0 */
 int vbmf_sparse_lower_bound(vbmf_ctx* ctx, int clamp, double* lb);
 
+/* ---- preprocess (src/util.jl:73-86; examples/mil_util.jl:829) fused into the upload -------------------------
+ * scaleY (:36-54: row mean / sqrt(row variance, n-1), variance <= 1e-15 -> 1, |y - mu| <= 1e-8 -> 0), drop the rows whose
+ * scaled absolute sum is < 1e-5 (:75-78), multiply by lambda (:86).  Dropping rows changes L, which a context is
+ * created with, hence two steps: open() uploads the caller's fp64 Y ONCE, keeps it resident on the device and
+ * returns the kept-row count; the caller creates the context with that L and set_Y_preprocessed() tiles the kept
+ * rows from the resident copy, transform applied on the fly (no second upload, no L x M temporaries). */
+typedef struct vbmf_prep vbmf_prep;
+int vbmf_preprocess_open(vbmf_prep** out, int device, const double* Y, int64_t L, int64_t M, int64_t ldY, int64_t* L_used);
+/* optional read-back: kept rows (0-based, L_used of them), row means and denominators (L each); any may be NULL */
+int vbmf_preprocess_rows(const vbmf_prep* plan, int64_t* used_rows0, double* mu, double* den);
+int vbmf_set_Y_preprocessed(vbmf_ctx* ctx, const vbmf_prep* plan, double lambda);
+int vbmf_preprocess_close(vbmf_prep* plan);
+
 /* ---- multi-GPU: one process per GPU, Y row-sharded, RCCL all-reduce of Y'B and of the Grams ---- */
 #define VBMF_UNIQUE_ID_BYTES 128
 int vbmf_comm_unique_id(void* id128);                       /* rank 0 creates, host broadcasts */

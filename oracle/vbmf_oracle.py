@@ -265,6 +265,26 @@ def vbls_(Y, p, niter):
     return p.AHat
 
 
+def scaleY(Y):
+    """src/util.jl:36-54: rows standardised with the row mean and the (n-1) row variance; variances <= 1e-15 -> 1,
+    centred entries <= 1e-8 in magnitude -> 0."""
+    Y = np.asarray(Y, dtype=np.float64)
+    mu = Y.mean(axis=1, keepdims=True)
+    den = Y.var(axis=1, ddof=1, keepdims=True)
+    den = np.where(np.abs(den) <= 1e-15, 1.0, den)
+    nom = Y - mu
+    nom[np.abs(nom) <= 1e-8] = 0.0
+    return nom / np.sqrt(den)
+
+
+def preprocess(Y, lam, return_rows=False):
+    """src/util.jl:73-86: scaleY, drop the rows whose absolute sum is < 1e-5, multiply by lambda."""
+    sY = scaleY(Y)
+    used = np.nonzero(np.abs(sY).sum(axis=1) >= 1e-5)[0]
+    out = lam * sY[used, :]
+    return (out, used) if return_rows else out
+
+
 def copy_vbmf_params(Y, old, rng=None):
     """examples/mil_util.jl:212-236: fresh parameters for a new Y keeping BHat, SigmaB, CB, invCB [, gamma, delta]."""
     if isinstance(old, vbmf_parameters):

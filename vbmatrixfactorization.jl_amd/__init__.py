@@ -31,6 +31,7 @@ from typing import Optional
 import numpy as np
 
 from . import capi, dist
+from .capi import PreprocessPlan
 from .capi import (Context, VbmfError, VBMF_Y_F32, VBMF_Y_BF16, VBMF_FACTOR_AUTO, VBMF_FACTOR_BF16,
                    VBMF_FACTOR_BF16X2, VBMF_VARIANT_SPARSE_DIAG, STEP_A, STEP_B, STEP_CA, STEP_CB, STEP_SIGMA2,
                    SSTEP_A, SSTEP_B, SSTEP_CA, SSTEP_CB, SSTEP_SIGMA)
@@ -493,3 +494,39 @@ def copy_vbmf_params(Y, old_params, rng=None):
     p.BHat, p.SigmaB = old_params.BHat.copy(), old_params.SigmaB.copy()
     p.CB, p.invCB = old_params.CB.copy(), old_params.invCB.copy()
     return p
+
+
+# =================================================================================================
+# Pre-processing -- src/util.jl:36-97 (the step before the factorization: examples/mil_util.jl:829)
+# =================================================================================================
+def scaleY(Y):
+    """scaleY -- src/util.jl:36-54 (host array in, host array out, like the reference)."""
+    Y = np.asarray(Y, dtype=np.float64)
+    mu = Y.mean(axis=1, keepdims=True)
+    den = Y.var(axis=1, ddof=1, keepdims=True)
+    den = np.where(np.abs(den) <= 1e-15, 1.0, den)
+    nom = Y - mu
+    nom[np.abs(nom) <= 1e-8] = 0.0
+    return nom / np.sqrt(den)
+
+
+def preprocess(Y, lam, verb=False):
+    """preprocess -- src/util.jl:73-86 with the reference's call shape (returns lambda * scaled kept rows as a host
+    array).  To avoid materialising it, use `preprocessed_session`, which standardises, filters and scales inside the
+    upload (PreprocessPlan + Context.set_Y_preprocessed) and never builds the L x M temporaries."""
+    sY = scaleY(Y)
+    used = np.nonzero(np.abs(sY).sum(axis=1) >= 1e-5)[0]
+    if verb:
+        print(f"Original problem size: {Y.shape[0]} rows, {Y.shape[0] - used.size} rows not relevant and are not used.")
+    return lam * sY[used, :]
+
+
+def preprocessed_session(Y, lam, H, **ctx_kw):
+    """Device-side preprocess: returns (Session over the pre-processed matrix, kept rows 0-based).  The Session's
+    ctx holds lambda * scaleY(Y)[kept rows] in the device dtype; use Session.run / push / pull with parameters
+    created for L = len(kept rows)."""
+    with PreprocessPlan(Y) as plan:
+        rows, _, _ = plan.rows()
+        s = Session(plan.L_used, plan.M, int(H), **ctx_kw)
+        s.ctx.set_Y_preprocessed(plan, lam)
+    return s, rows

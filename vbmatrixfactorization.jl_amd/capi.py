@@ -26,7 +26,8 @@ SYMBOLS = [
     "vbmf_elbo", "vbmf_comm_unique_id", "vbmf_comm_init", "vbmf_comm_set_transport", "vbmf_profile_enable", "vbmf_profile_read",
     "vbmf_pass_bytes", "vbmf_device_sync", "vbmf_debug_peek", "vbmf_debug_time_pass",
     "vbmf_sparse_set_state", "vbmf_sparse_get_state", "vbmf_sparse_step", "vbmf_sparse_run", "vbmf_sparse_run_fixed_basis",
-    "vbmf_sparse_lower_bound",
+    "vbmf_sparse_lower_bound", "vbmf_preprocess_open", "vbmf_preprocess_rows", "vbmf_set_Y_preprocessed",
+    "vbmf_preprocess_close",
 ]
 SSTEP_A, SSTEP_B, SSTEP_CA, SSTEP_CB, SSTEP_SIGMA = 1, 2, 4, 8, 16
 PEEK_P, PEEK_Q, PEEK_A32, PEEK_B32, PEEK_FA, PEEK_FB, PEEK_Y1, PEEK_Y2, PEEK_DIMS = range(9)
@@ -111,6 +112,10 @@ def lib():
     L.vbmf_sparse_step.argtypes = [vp, i32]
     L.vbmf_sparse_run.argtypes = [vp, i64, C.c_double, i32, C.POINTER(i64), dp, dp]
     L.vbmf_sparse_lower_bound.argtypes = [vp, i32, dp]
+    L.vbmf_preprocess_open.argtypes = [C.POINTER(vp), i32, dp, i64, i64, i64, C.POINTER(i64)]
+    L.vbmf_preprocess_rows.argtypes = [vp, C.POINTER(i64), dp, dp]
+    L.vbmf_set_Y_preprocessed.argtypes = [vp, vp, C.c_double]
+    L.vbmf_preprocess_close.argtypes = [vp]
     for name in SYMBOLS:
         if name not in ("vbmf_default_opts", "vbmf_last_error"):
             getattr(L, name).restype = C.c_int
@@ -128,6 +133,44 @@ def _fcol(a, shape=None):
     if shape is not None and tuple(a.shape) != tuple(shape):
         raise ValueError(f"expected shape {shape}, got {a.shape}")
     return np.asfortranarray(a)
+
+
+class PreprocessPlan:
+    """preprocess (src/util.jl:73-86) fused into the upload: holds the caller's fp64 Y on the device with its row
+    statistics and the kept rows; Context.set_Y_preprocessed tiles from it.  Use as a context manager."""
+
+    def __init__(self, Y, device=0):
+        Yf = np.asfortranarray(Y, dtype=np.float64)
+        self.L, self.M = Yf.shape
+        self._lib = lib()
+        self._h = C.c_void_p()
+        n = C.c_int64()
+        rc = self._lib.vbmf_preprocess_open(C.byref(self._h), device, _dptr(Yf), self.L, self.M, self.L, C.byref(n))
+        if rc != 0:
+            raise VbmfError(rc, self._lib.vbmf_last_error(None).decode())
+        self.L_used = n.value
+
+    def rows(self):
+        r = np.empty(self.L_used, dtype=np.int64); mu = np.empty(self.L); den = np.empty(self.L)
+        self._lib.vbmf_preprocess_rows(self._h, r.ctypes.data_as(C.POINTER(C.c_int64)), _dptr(mu), _dptr(den))
+        return r, mu, den
+
+    def close(self):
+        if self._h:
+            self._lib.vbmf_preprocess_close(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Context:
@@ -176,6 +219,9 @@ class Context:
     def set_Y(self, Y):
         Y = _fcol(Y, (self.L, self.M))
         self._chk(self._lib.vbmf_set_Y(self._h, _dptr(Y), Y.shape[0]))
+
+    def set_Y_preprocessed(self, plan, lam):
+        self._chk(self._lib.vbmf_set_Y_preprocessed(self._h, plan._h, float(lam)))
 
     def set_Y_synthetic(self, seed, Hstar, noise_std):
         self._chk(self._lib.vbmf_set_Y_synthetic(self._h, seed, Hstar, noise_std))

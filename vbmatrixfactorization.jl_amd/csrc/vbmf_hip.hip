@@ -36,6 +36,7 @@
 #include "sparse_kernels.hpp"
 #include "stream_gemm.hpp"
 #include "tile_kernels.hpp"
+#include "prep_kernels.hpp"
 
 using namespace vbmf;
 
@@ -773,6 +774,84 @@ int vbmf_set_Y(vbmf_ctx* c, const double* Y, int64_t ldY) {
     }
     hipFree(stage);
     if (rc != VBMF_OK) return rc;
+    return finish_Y(c);
+}
+
+// ---- preprocess (src/util.jl:36-54, 73-86) fused into the upload ---------------------------------
+struct vbmf_prep {
+    int device = 0;
+    int64_t L = 0, M = 0, L_used = 0;
+    double* Y = nullptr;            // resident fp64 copy, column-major, ld = L
+    double *mu = nullptr, *den = nullptr;
+    long long* rows = nullptr;      // kept rows (device)
+    std::vector<int64_t> rows_host;
+    std::vector<double> mu_host, den_host;
+};
+
+int vbmf_preprocess_open(vbmf_prep** out, int device, const double* Y, int64_t L, int64_t M, int64_t ldY, int64_t* L_used) {
+    if (!out || !Y || L <= 0 || M <= 0 || ldY < L) return VBMF_ERR_INVALID;
+    *out = nullptr;
+    if (hipSetDevice(device) != hipSuccess) { g_create_error = "vbmf_preprocess_open: bad device"; return VBMF_ERR_NO_DEVICE; }
+    vbmf_prep* p = new vbmf_prep();
+    p->device = device; p->L = L; p->M = M;
+    double* part = nullptr; unsigned char* keep = nullptr; double* rowsum = nullptr;
+    auto bail = [&](const char* what) { g_create_error = std::string("vbmf_preprocess_open: ") + what; hipFree(part); hipFree(keep); hipFree(rowsum);
+                                        hipFree(p->Y); hipFree(p->mu); hipFree(p->den); hipFree(p->rows); delete p; return VBMF_ERR_HIP; };
+    if (hipMalloc((void**)&p->Y, (size_t)L * M * 8) != hipSuccess) return bail("device allocation of the fp64 copy failed");
+    if (hipMalloc((void**)&p->mu, (size_t)L * 8) != hipSuccess || hipMalloc((void**)&p->den, (size_t)L * 8) != hipSuccess ||
+        hipMalloc((void**)&rowsum, (size_t)L * 8) != hipSuccess || hipMalloc((void**)&keep, (size_t)L) != hipSuccess ||
+        hipMalloc((void**)&part, (size_t)PREP_CHUNKS * L * 8) != hipSuccess) return bail("allocation failed");
+    if (hipMemcpy2D(p->Y, (size_t)L * 8, Y, (size_t)ldY * 8, (size_t)L * 8, (size_t)M, hipMemcpyHostToDevice) != hipSuccess) return bail("upload failed");
+    const dim3 g((unsigned)((L + 255) / 256), PREP_CHUNKS), gf((unsigned)((L + 255) / 256));
+    double* outs[3] = {p->mu, p->den, rowsum};
+    for (int what = 0; what < 3; ++what) {
+        hipLaunchKernelGGL(prep_row_partial_kernel, g, dim3(256), 0, 0, p->Y, (long long)L, (long long)M, (long long)L, what, p->mu, p->den, part);
+        hipLaunchKernelGGL(prep_row_fold_kernel, gf, dim3(256), 0, 0, part, (long long)L, (long long)M, what, outs[what], keep);
+    }
+    std::vector<unsigned char> kh((size_t)L);
+    p->mu_host.resize((size_t)L); p->den_host.resize((size_t)L);
+    if (hipMemcpy(kh.data(), keep, (size_t)L, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(p->mu_host.data(), p->mu, (size_t)L * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(p->den_host.data(), p->den, (size_t)L * 8, hipMemcpyDeviceToHost) != hipSuccess) return bail("statistics kernels failed");
+    for (int64_t l = 0; l < L; ++l) if (kh[(size_t)l]) p->rows_host.push_back(l);
+    p->L_used = (int64_t)p->rows_host.size();
+    if (hipMalloc((void**)&p->rows, std::max<size_t>(8, (size_t)p->L_used * 8)) != hipSuccess) return bail("allocation failed");
+    if (p->L_used && hipMemcpy(p->rows, p->rows_host.data(), (size_t)p->L_used * 8, hipMemcpyHostToDevice) != hipSuccess) return bail("upload failed");
+    hipFree(part); hipFree(keep); hipFree(rowsum);
+    if (L_used) *L_used = p->L_used;
+    *out = p;
+    return VBMF_OK;
+}
+
+int vbmf_preprocess_rows(const vbmf_prep* p, int64_t* used_rows0, double* mu, double* den) {
+    if (!p) return VBMF_ERR_INVALID;
+    if (used_rows0) memcpy(used_rows0, p->rows_host.data(), (size_t)p->L_used * 8);
+    if (mu) memcpy(mu, p->mu_host.data(), (size_t)p->L * 8);
+    if (den) memcpy(den, p->den_host.data(), (size_t)p->L * 8);
+    return VBMF_OK;
+}
+
+int vbmf_preprocess_close(vbmf_prep* p) {
+    if (!p) return VBMF_ERR_INVALID;
+    hipSetDevice(p->device);
+    hipFree(p->Y); hipFree(p->mu); hipFree(p->den); hipFree(p->rows);
+    delete p;
+    return VBMF_OK;
+}
+
+int vbmf_set_Y_preprocessed(vbmf_ctx* c, const vbmf_prep* p, double lambda) {
+    if (!c || !p) return VBMF_ERR_INVALID;
+    if (p->device != c->o.device) FAIL(c, VBMF_ERR_INVALID, "vbmf_set_Y_preprocessed: plan lives on another device");
+    if (p->M != c->M) FAIL(c, VBMF_ERR_INVALID, "vbmf_set_Y_preprocessed: M mismatch");
+    if (c->Lg != p->L_used || c->o.row_offset < 0 || c->o.row_offset + c->L > p->L_used)
+        FAIL(c, VBMF_ERR_INVALID, "vbmf_set_Y_preprocessed: the context (or, row-sharded, L_global) must have the plan's kept-row count %lld",
+             (long long)p->L_used);
+    HIPCHK(c, hipSetDevice(c->o.device));
+    HIPCHK(c, hipDeviceSynchronize());                      // the plan's kernels ran on the null stream
+    double* tr = c->st + c->lay.scal() + S_TRYY;
+    HIPCHK(c, hipMemsetAsync(tr, 0, sizeof(double), c->stream));
+    PrepSrc src{p->Y, (long long)p->L, p->rows, p->mu, p->den, lambda, (long long)c->L, (long long)c->M, (long long)c->o.row_offset};
+    TRY(build_tiles(c, src, 0, c->M, tr));
     return finish_Y(c);
 }
 
