@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--factor", default="auto", choices=["auto", "bf16", "bf16x2"])
     ap.add_argument("--splits", type=int, default=0, help="split-K of the Y'B pass (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shard-of", type=int, default=0,
+                    help="developer aid on ONE GPU: run rank 0's share of an N-rank strong-scaling job (L/N rows, "
+                         "L_global = L, 1-rank communicator => the collective code path); an upper bound for N GPUs")
     ap.add_argument("--cpu-rows", type=int, default=25000, help="row sample of the CPU baseline")
     ap.add_argument("--cpu-sweeps", type=int, default=3)
     return ap.parse_args()
@@ -92,6 +95,11 @@ def cpu_baseline(ctx, L, M, H, rows, sweeps, seed):
 
 def main():
     a = parse()
+    # stdout carries exactly ONE line, the JSON result: libraries that print there (RCCL writes a version banner on
+    # communicator creation) are sent to stderr for the duration of the run
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -121,18 +129,21 @@ def main():
         f_dtype = capi.VBMF_FACTOR_AUTO
 
     # row shard of this rank (equal counts, remainder to the first shards: SURVEY 8e)
-    base, rem = divmod(L, world)
+    emu = a.shard_of if (a.shard_of > 1 and world == 1) else 0
+    base, rem = divmod(L, emu or world)
     L_loc = base + (1 if rank < rem else 0)
     row0 = rank * base + min(rank, rem)
 
     sparse = (a.config == "cfg5")
     ctx = capi.Context(L_loc, M, H, y_dtype=y_dtype, factor_dtype=f_dtype, device=local_rank, nranks=world,
-                       rank=rank, L_global=L, row_offset=row0, pass1_splits=a.splits,
+                       rank=rank, L_global=(L_loc if emu else L), row_offset=row0, pass1_splits=a.splits,
                        variant=capi.VBMF_VARIANT_SPARSE_DIAG if sparse else capi.VBMF_VARIANT_BASIC)
     if world > 1:
         uid = [capi.Context.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         ctx.comm_init(uid[0])
+    elif emu:
+        ctx.comm_init(capi.Context.unique_id())
 
     ctx.set_Y_synthetic(20170101, H, 0.05)
     rng = np.random.default_rng(20170102)
@@ -219,6 +230,9 @@ def main():
         },
         "final": {"sigma2": s["sigma2"], "d": d},
     }
+    if emu:
+        out["config"]["emulation"] = (f"rank 0's share of a {emu}-rank strong-scaling run on one GPU ({L_loc} of {L} rows, "
+                                      "1-rank RCCL communicator, L_global = the share): per-rank compute only, no inter-GPU latency")
     if sparse:
         out["metric"] = "VB iterations/sec (vbmf_sparse!, diagonal branch)"
         out["config"]["workload"] = out["config"]["workload"].replace("vbmf! sweep, est_covs=est_var=true", "vbmf_sparse! sweep (full_cov=false, diag_var=false, est_cb=true)")
@@ -230,8 +244,10 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -40,7 +40,7 @@ def test_preprocess_fused_upload(pkg, ydt, shape):
     # host mirror with the reference's call shape
     assert np.array_equal(pkg.preprocess(Y, lam), ref)
     dt = pkg.VBMF_Y_F32 if ydt == "f32" else pkg.VBMF_Y_BF16
-    s, rows = pkg.preprocessed_session(Y, lam, 4, y_dtype=dt)
+    s, rows = pkg.preprocessed_session(Y, lam, 4, y_dtype=dt, factor_dtype=pkg.VBMF_FACTOR_AUTO)
     try:
         assert np.array_equal(rows, used) and s.L == used.size
         got = s.ctx.get_Y()
@@ -66,7 +66,7 @@ def test_preprocess_then_factorize(pkg):
     As = np.zeros((M, H)); As[np.arange(M), rng.integers(0, H, M)] = 1.0
     Y = (Bs @ As.T + 0.05 * rng.standard_normal((L, M))) * rng.uniform(0.5, 20.0, (L, 1)) + rng.uniform(-5, 5, (L, 1))
     Y[7] = 2.0
-    s, rows = pkg.preprocessed_session(Y, 1.0, H, y_dtype=pkg.VBMF_Y_F32)
+    s, rows = pkg.preprocessed_session(Y, 1.0, H, y_dtype=pkg.VBMF_Y_F32, factor_dtype=pkg.VBMF_FACTOR_AUTO)
     try:
         Ys = np.ascontiguousarray(s.ctx.get_Y())
         po = O.vbmf_init(Ys, H, ca=0.1, cb=0.1, sigma2=0.1, rng=np.random.default_rng(3), materialize_yhat=False)

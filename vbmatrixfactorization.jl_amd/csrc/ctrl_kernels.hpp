@@ -34,7 +34,8 @@ struct StateLayout {
     __host__ __device__ long long total() const { return scal() + 32; }
 };
 enum : int { S_SIGMA2 = 0, S_TRYY, S_LOGDET_SA, S_LOGDET_SB, S_LAMB_PREV, S_LAMB_NEW, S_LAMD, S_D, S_ELBO,
-             S_TRDOT, S_RESID, S_TRYBA };
+             S_TRDOT, S_RESID, S_TRYBA,
+             S_LOGDET_SA_SHADOW = 20 };      // 12..18: sparse_kernels.hpp
 enum : int { I_STOP = 0, I_ITERS = 1, I_ERR = 2, I_NITER = 3 };
 
 __device__ __forceinline__ double block_sum(double v, double* red) {
@@ -264,9 +265,12 @@ __device__ __forceinline__ int load_stop(const int* ints) {
 
 // which = 0: SigmaA from (GB, SigmaB, ca), N = L_global.  which = 1: SigmaB from (GA, SigmaA, cb), N = M.
 // Needs T*T threads and (4*T*R + T*R) doubles of LDS at `lds`; every thread of the block must call it.
+// shadow (which = 0, H <= 128 only): SigmaA and its log-determinant go to the W0 scratch / the shadow scalar instead
+// of the state; commit_cov_a_kernel copies them over once it is known that the loop continues (ctrl_chain).
 template <int R, int T>
 __device__ __forceinline__ void ctrl_cov_dev(double* __restrict__ st, StateLayout lay, int H, int which, double N,
-                                             float* __restrict__ S32, int* __restrict__ ints, double* lds) {
+                                             float* __restrict__ S32, int* __restrict__ ints, double* lds,
+                                             bool shadow = false) {
     __shared__ double red[16];
     if (load_stop(ints)) return;
     constexpr int NP = T * R;
@@ -274,7 +278,7 @@ __device__ __forceinline__ void ctrl_cov_dev(double* __restrict__ st, StateLayou
     const int tx = threadIdx.x % T, ty = threadIdx.x / T;
     const double* G = st + (which == 0 ? lay.GB() : lay.GA());
     const double* Sother = st + (which == 0 ? lay.SB() : lay.SA());
-    double* Sself = st + (which == 0 ? lay.SA() : lay.SB());
+    double* Sself = st + (which == 0 ? (shadow ? lay.W0() : lay.SA()) : lay.SB());
     const double* cdiag = st + (which == 0 ? lay.ca() : lay.cb());
     double* scal = st + lay.scal();
     const double sigma2 = scal[S_SIGMA2];
@@ -342,7 +346,17 @@ __device__ __forceinline__ void ctrl_cov_dev(double* __restrict__ st, StateLayou
     }
     ld = block_sum(ld, red);
     if (bad) atomicExch(ints + I_ERR, 1);
-    if (threadIdx.x == 0) scal[which == 0 ? S_LOGDET_SA : S_LOGDET_SB] = (double)H * log(sigma2) - ld;
+    if (threadIdx.x == 0)
+        scal[which == 0 ? (shadow ? S_LOGDET_SA_SHADOW : S_LOGDET_SA) : S_LOGDET_SB] = (double)H * log(sigma2) - ld;
+}
+
+// the loop continues: make the speculative SigmaA of ctrl_chain the state's
+__global__ __launch_bounds__(256) void commit_cov_a_kernel(double* __restrict__ st, StateLayout lay, const int* __restrict__ ints) {
+    if (load_stop(ints)) return;
+    const long long n = lay.n2();
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        st[lay.SA() + i] = st[lay.W0() + i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) st[lay.scal() + S_LOGDET_SA] = st[lay.scal() + S_LOGDET_SA_SHADOW];
 }
 
 template <int R, int T>
@@ -548,9 +562,11 @@ __global__ __launch_bounds__(1024) void eig_power_kernel(double* __restrict__ st
 // flags: bit0 est_covs->CA, bit1 est_covs->CB, bit2 est_var, bit3 compute d + loop bookkeeping,
 //        bit4 tr(Y'BA') from the Gram identity tr(KB o GB) (else from scal[S_TRDOT]),
 //        bit5 S_LAMB_PREV already holds lambda_max of the old B'B (no rotation from S_LAMB_NEW)
+//        bit6 split schedule (ctrl_chain): the d / loop part (bit3) is done by ctrl_loop_dev in another workgroup;
+//             this call only files sigma2 / ELBO / residual in trace row it_row
 __device__ __forceinline__ void ctrl_end_dev(double* __restrict__ st, StateLayout lay, int H, double Lg, double M,
                                              int flags, double eps, double* __restrict__ trace,
-                                             int* __restrict__ ints) {
+                                             int* __restrict__ ints, int it_row = -1) {
     __shared__ double red[16];
     if (load_stop(ints)) return;
     const int Hp = lay.Hp;
@@ -598,7 +614,9 @@ __device__ __forceinline__ void ctrl_end_dev(double* __restrict__ st, StateLayou
         scal[S_ELBO] = F;
         scal[S_RESID] = resid;
         scal[S_TRYBA] = trYBA;
-        if (flags & 8) {
+        if (flags & 64) {
+            if (trace) { trace[4 * it_row + 1] = sigma2; trace[4 * it_row + 2] = F; trace[4 * it_row + 3] = resid; }
+        } else if (flags & 8) {
             const double d = sqrt(scal[S_LAMD] / scal[S_LAMB_PREV]);
             scal[S_D] = d;
             if (!(flags & 32)) scal[S_LAMB_PREV] = scal[S_LAMB_NEW];   // (32: lambda_max of the old B is written there directly)
@@ -628,7 +646,8 @@ struct CtrlArgs {
     float* S32;            // SigmaA/sigma2 (pass 1) or SigmaB/sigma2 (pass 2) table for the post kernel
     double Lg, M, eps;
     int H, spectral, end_flags;
-    int mode;              // CTRL_* bits; 0: no control workgroup in this launch
+    int mode;              // CTRL_* bits; 0: no control workgroups in this launch
+    int it_row;            // sweep index (trace row) the CTRL_PREV_END part finalises
 };
 // Schedule inside vbmf_run (sweep j; B_{j-1} is the factor the sweep starts from):
 //   pass 1 of sweep j : [lambda_max(dB'dB) of sweep j-1, ctrl_end of sweep j-1]  then  SigmaA of sweep j
@@ -637,17 +656,45 @@ struct CtrlArgs {
 // so each pass carries a chain of similar length (~75 / ~65 us at H = 64).
 enum : int { CTRL_PREV_END = 1, CTRL_COV_A = 2, CTRL_COV_B = 4, CTRL_EIG_BOLD = 8 };
 
-template <int R>
-__device__ __forceinline__ void ctrl_chain(const CtrlArgs& a, void* lds) {
-    if (a.mode & CTRL_PREV_END) {
-        eig_dev<R>(a.st, a.lay, a.H, a.spectral, 0, a.ints, reinterpret_cast<float*>(lds), S_LAMD);
-        ctrl_end_dev(a.st, a.lay, a.H, a.Lg, a.M, a.end_flags | 32, a.eps, a.trace, a.ints);
+// d = ||B_old - B_new||_2 / ||B_old||_2 (src/util.jl:27-29) and the loop test (src/vbmf.jl:193) of sweep it_row
+__device__ __forceinline__ void ctrl_loop_dev(double* __restrict__ st, StateLayout lay, double eps,
+                                              double* __restrict__ trace, int* __restrict__ ints, int it_row) {
+    if (load_stop(ints)) return;
+    if (threadIdx.x == 0) {
+        double* scal = st + lay.scal();
+        const double d = sqrt(scal[S_LAMD] / scal[S_LAMB_PREV]);
+        scal[S_D] = d;
+        if (trace) trace[4 * it_row + 0] = d;
+        ints[I_ITERS] = it_row + 1;
+        if (!(d > eps) || it_row + 1 >= ints[I_NITER])                      // NaN d exits too
+            __hip_atomic_store(ints + I_STOP, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (a.mode & CTRL_COV_A) ctrl_cov_dev<R, 16>(a.st, a.lay, a.H, 0, a.Lg, a.S32, a.ints, reinterpret_cast<double*>(lds));
-    if (a.mode & CTRL_COV_B) ctrl_cov_dev<R, 16>(a.st, a.lay, a.H, 1, a.M, a.S32, a.ints, reinterpret_cast<double*>(lds));
-    if (a.mode & CTRL_EIG_BOLD) {
-        __syncthreads();
-        eig_dev<R>(a.st, a.lay, a.H, a.spectral, 1, a.ints, reinterpret_cast<float*>(lds), S_LAMB_PREV);
+    __threadfence();
+    __syncthreads();
+}
+
+// The chain is split over the launch's first TWO workgroups (what bounds a pass launch on a short row shard is this
+// chain, not the streaming: 83 us per launch on a 12.5k-row shard before the split):
+//   part 0:  [CA, CB, sigma2, ELBO of the previous sweep]  ->  SigmaA (speculative: into the shadow, committed by
+//            commit_cov_a_kernel after the launch iff the loop continues)            |  SigmaB
+//   part 1:  lambda_max(dB'dB) -> d, trace, iteration count, stop                    |  lambda_max(B_old'B_old)
+// Part 1's stop decision does not wait for part 0 and vice versa; CA/CB/sigma2 belong to the finished sweep and are
+// due whether or not the loop stops, SigmaA belongs to the next one and is not.
+template <int R>
+__device__ __forceinline__ void ctrl_chain(const CtrlArgs& a, void* lds, int part) {
+    if (part == 0) {
+        if (a.mode & CTRL_PREV_END)
+            ctrl_end_dev(a.st, a.lay, a.H, a.Lg, a.M, (a.end_flags & ~8) | 64, a.eps, a.trace, a.ints, a.it_row);
+        if (a.mode & CTRL_COV_A)
+            ctrl_cov_dev<R, 16>(a.st, a.lay, a.H, 0, a.Lg, a.S32, a.ints, reinterpret_cast<double*>(lds), true);
+        if (a.mode & CTRL_COV_B) ctrl_cov_dev<R, 16>(a.st, a.lay, a.H, 1, a.M, a.S32, a.ints, reinterpret_cast<double*>(lds));
+    } else {
+        if (a.mode & CTRL_PREV_END) {
+            eig_dev<R>(a.st, a.lay, a.H, a.spectral, 0, a.ints, reinterpret_cast<float*>(lds), S_LAMD);
+            ctrl_loop_dev(a.st, a.lay, a.eps, a.trace, a.ints, a.it_row);
+        }
+        if (a.mode & CTRL_EIG_BOLD)
+            eig_dev<R>(a.st, a.lay, a.H, a.spectral, 1, a.ints, reinterpret_cast<float*>(lds), S_LAMB_PREV);
     }
 }
 

@@ -375,8 +375,9 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restric
 // out[i] = sum_s slabs[s][i]   (fp32, fixed order => deterministic).  16-byte loads, whole-chip grid:
 // the split-K partials of the Y'B pass (nsplit x 2.5 MB at 10k x 64) are folded here at HBM/L2 rate
 // instead of inside the 80-block post kernel.  n must be a multiple of 4 (it is: Hp * Xp).
-__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slabs, int nslab,
-                                                       long long slabStride, float* __restrict__ out, long long n,
+// out may be slab 0 itself (element-wise: every thread reads its element of all slabs, then writes it).
+__global__ __launch_bounds__(256) void slab_sum_kernel(const float* slabs, int nslab,
+                                                       long long slabStride, float* out, long long n,
                                                        const int* __restrict__ stop) {
     if (stop && *stop) return;
     const long long n4 = n >> 2;

@@ -27,7 +27,7 @@
 //     register is 32 consecutive x of one h row -> two 128-byte segments per store instruction.
 //   * Split-K partials go to per-split slabs with plain stores (deterministic; the consumer sums them
 //     while it loads), not atomics.
-//   * Workgroup 0 of a launch may run the sweep's H x H control chain (ctrl_kernels.hpp, CtrlArgs)
+//   * Workgroups 0 and 1 of a launch may run the sweep's H x H control chain (ctrl_kernels.hpp, CtrlArgs)
 //     instead of streaming: its inputs are complete before the launch and its outputs are needed only
 //     after it, so the chain overlaps the pass for free.
 //   * Grid: per-CU throughput is latency-bound, so time = the most loaded CU: the planner (host) picks
@@ -55,15 +55,15 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const uint4* __restric
     static_assert(PIPE_D % DY == 0 && DY % DF == 0, "ring depths must divide the padding quantum");
     constexpr bool FINE = (NH >= 4);
     int bid = blockIdx.x;
-    if (ctrl.mode != 0) {                                 // launch carries a control workgroup (dispatched first)
-        if (bid == 0) {
+    if (ctrl.mode != 0) {                                 // launch carries two control workgroups (dispatched first)
+        if (bid < 2) {
             if constexpr (RCTRL > 0) {
                 extern __shared__ __attribute__((aligned(16))) unsigned char ctrl_lds[];
-                ctrl_chain<RCTRL>(ctrl, ctrl_lds);
+                ctrl_chain<RCTRL>(ctrl, ctrl_lds, bid);
             }
             return;
         }
-        bid -= 1;
+        bid -= 2;
     }
     if (stop && *stop) return;
 

@@ -76,7 +76,8 @@ struct vbmf_ctx {
     int64_t H1 = 0;
     bool has_mask = false;
     hipStream_t stream = nullptr;
-    bool in_run = false;              // inside vbmf_run: the control chain rides in workgroup 0 of the pass launches
+    bool in_run = false;              // inside vbmf_run: the control chain rides in workgroups 0-1 of the pass launches
+    int64_t ends_enqueued = 0;        // sweeps whose closing control step has been enqueued in this run (trace row)
     bool tail_pending = false;        // eig + ctrl_end of the last enqueued sweep not issued yet
     int run_flags = 0;
     double run_eps = 0.0;
@@ -162,8 +163,8 @@ template <> struct StreamCfg<8> { static constexpr int NXWc = 2; static constexp
 
 static int nxw_of(int NH) { return NH == 1 ? 8 : (NH == 8 ? 2 : 4); }              // = StreamCfg<NH>::NXWc
 static int dy_of(int NH) { return NH == 1 ? 3 : (NH == 2 ? 6 : (NH == 4 ? 4 : 2)); } // = StreamCfg<NH>::DYc
-// one CU is left to the control workgroup that rides in each pass launch
-constexpr int NUM_CU = 255;
+// two CUs are left to the control workgroups that ride in each pass launch
+constexpr int NUM_CU = 254;
 
 // Split-K plan.  A CU streams at most ~24-30 GB/s with this kernel (so ~220+ busy CUs are needed to
 // saturate HBM), and a pass ends with its most loaded CU, so it takes
@@ -248,13 +249,13 @@ static int launch_stream(vbmf_ctx* c, int pass, int ctrl_mode = 0) {
     const long long ld = (long long)d.XT * 32;
     const int XG = d.XT / nxw_of(c->NH);
     const int bps = (XG + 3) / 4;
-    const int grid = bps * d.nsplit + (ctrl_mode ? 1 : 0);
+    const int grid = bps * d.nsplit + (ctrl_mode ? 2 : 0);
     CtrlArgs ca{};
     ca.st = c->st; ca.lay = c->lay; ca.ints = c->ints; ca.trace = c->run_trace;
     ca.S32 = pass == 0 ? c->SA32 : c->SB32;
     ca.Lg = (double)c->Lg; ca.M = (double)c->M; ca.eps = c->run_eps;
     ca.H = (int)c->H; ca.spectral = (c->o.reference_compat & VBMF_COMPAT_SPECTRAL_DELTA) ? 1 : 0;
-    ca.end_flags = c->run_flags; ca.mode = ctrl_mode;
+    ca.end_flags = c->run_flags; ca.mode = ctrl_mode; ca.it_row = (int)c->ends_enqueued;
     const size_t lds = ctrl_mode ? ctrl_lds_bytes(c->NH) : 0;
     prof_begin(c, pass);
     DISPATCH_MODE(c->mode, DISPATCH_NH(c->NH, {
@@ -466,7 +467,11 @@ static int do_update_A(vbmf_ctx* c, bool reuse_P = false) {
         TRY(launch_ctrl_cov(c, 0));
     } else if (fused_ctrl(c)) {
         TRY(launch_stream(c, 0, CTRL_COV_A | (c->tail_pending ? CTRL_PREV_END : 0)));
+        if (c->tail_pending) ++c->ends_enqueued;
         c->tail_pending = false;
+        // SigmaA was computed speculatively beside the previous sweep's stop test: commit it iff the loop continues
+        hipLaunchKernelGGL(commit_cov_a_kernel, dim3(8), dim3(256), 0, c->stream, c->st, c->lay, c->ints);
+        HIPCHK(c, hipGetLastError());
     } else {
         TRY(launch_ctrl_cov(c, 0));
         TRY(launch_stream(c, 0));
@@ -493,6 +498,17 @@ static int do_update_A(vbmf_ctx* c, bool reuse_P = false) {
     return VBMF_OK;
 }
 
+// split-K partials of the Y*A pass (short row shards): fold them into slab 0 at HBM/L2 rate; the latency-bound post
+// kernel then reads one slab (measured on a 12.5k-row shard: post_gram 85 -> 15 us)
+static int fold_Q_slabs(vbmf_ctx* c) {
+    if (c->d2.nsplit <= 1) return VBMF_OK;
+    const long long n = (long long)c->Hp * c->d2.XT * 32;
+    hipLaunchKernelGGL(slab_sum_kernel, dim3(grid_for(n / 4, 256, 2048)), dim3(256), 0, c->stream, c->Q, c->d2.nsplit, n, c->Q, n,
+                       c->ints + I_STOP);
+    HIPCHK(c, hipGetLastError());
+    return VBMF_OK;
+}
+
 static int do_update_B(vbmf_ctx* c) {
     TRY(ensure_gram_A(c));
     if (fused_ctrl(c)) {
@@ -501,10 +517,11 @@ static int do_update_B(vbmf_ctx* c) {
         TRY(launch_ctrl_cov(c, 1));
         TRY(launch_stream(c, 1));
     }
+    TRY(fold_Q_slabs(c));
     if (fused_gram(c)) {
-        TRY(launch_post_gram(c, 1, c->Q, c->d2.nsplit));
+        TRY(launch_post_gram(c, 1, c->Q, 1));
     } else {
-        TRY(launch_post(c, 1, c->Q, c->d2.nsplit));
+        TRY(launch_post(c, 1, c->Q, 1));
         TRY(launch_gram(c, 1, c->B32[c->bcur ^ 1], c->B32[c->bcur], true));
     }
     c->bcur ^= 1;
@@ -1088,6 +1105,7 @@ int vbmf_run(vbmf_ctx* c, int64_t niter, double eps, int est_covs, int est_var, 
     const int flags = (est_covs ? 3 : 0) | (est_var ? 4 : 0) | 8 | 16;
     const int bstart = c->bcur;
     c->in_run = true;
+    c->ends_enqueued = 0;
     c->tail_pending = false;
     c->run_flags = flags;
     c->run_eps = eps;
@@ -1106,6 +1124,7 @@ int vbmf_run(vbmf_ctx* c, int64_t niter, double eps, int est_covs, int est_var, 
             } else if (fused_ctrl(c)) {
                 rc = launch_eig(c, 1, 0);
                 if (rc == VBMF_OK) rc = launch_ctrl_end(c, flags | 32, eps, trace_dev);
+                ++c->ends_enqueued;
             } else {
                 rc = launch_eig(c, 1, 1);
                 if (rc == VBMF_OK) rc = launch_ctrl_end(c, flags, eps, trace_dev);
@@ -1375,10 +1394,11 @@ static int do_sparse_update_B(vbmf_ctx* c) {
     TRY(ensure_gram_A(c));
     TRY(launch_sparse_cov_b(c));
     TRY(launch_stream(c, 1));
+    TRY(fold_Q_slabs(c));
     if (fused_gram(c)) {
-        TRY(launch_post_gram(c, 1, c->Q, c->d2.nsplit));
+        TRY(launch_post_gram(c, 1, c->Q, 1));
     } else {
-        TRY(launch_post(c, 1, c->Q, c->d2.nsplit));
+        TRY(launch_post(c, 1, c->Q, 1));
         TRY(launch_gram(c, 1, c->B32[c->bcur ^ 1], c->B32[c->bcur], false));
     }
     c->bcur ^= 1;
