@@ -10,7 +10,8 @@
 # Written for Julia >= 1.6 (the reference is Julia 0.5 syntax and does not parse on 1.x).
 module VBMatrixFactorizationHIP
 
-export vbmf_parameters, vbmf_init, vbmf, vbmf!, updateA!, updateB!, updateCA!, updateCB!, updateSigma2!, updateYHat!
+export vbmf_parameters, vbmf_init, vbmf, vbmf!, updateA!, updateB!, updateCA!, updateCB!, updateSigma2!, updateYHat!,
+       vbls!, copy_vbmf_params, preprocess_device, vbmf_on!
 
 const libvbmf = get(ENV, "VBMF_HIP_LIB", joinpath(@__DIR__, "..", "libvbmf_hip.so"))
 
@@ -173,6 +174,61 @@ function vbmf(Y::Array{Float64,2}, params_in::vbmf_parameters, niter::Int; kwarg
     params = copy(params_in)
     params.CA, params.CB = copy(params.CA), copy(params.CB)     # keep params_in reusable (see SURVEY App. A Q2)
     vbmf!(Y, params, niter; kwargs...)
+    return params
+end
+
+"vbls! -- examples/mil_util.jl:179-203 (vbmf_parameters branch): A/CA/sigma2 sweeps with B frozen; Y'B is formed once"
+function vbls!(Y::Array{Float64,2}, params::vbmf_parameters, niter::Int; diag_var::Bool = false, full_cov::Bool = false)
+    (diag_var || full_cov) && error("only full_cov=false, diag_var=false is built")
+    c = ctx_for(Y, params.H)
+    push!(c, params)
+    chk(c.h, ccall((:vbmf_run_fixed_basis, libvbmf), Cint, (Ptr{Cvoid}, Int64), c.h, niter))
+    pull!(c, params)
+    params.L * params.M <= (1 << 24) && updateYHat!(params, Y)                                # :201
+    return params.AHat
+end
+
+"copy_vbmf_params -- examples/mil_util.jl:212-236 (vbmf_parameters branch)"
+function copy_vbmf_params(Y::Array{Float64,2}, old_params::vbmf_parameters)
+    params = vbmf_init(Y, old_params.H, sigma2 = old_params.sigma2)
+    params.BHat = copy(old_params.BHat); params.SigmaB = copy(old_params.SigmaB)
+    params.CB = copy(old_params.CB); params.invCB = copy(old_params.invCB)
+    return params
+end
+
+"""
+preprocess -- src/util.jl:73-86 fused into the upload.  Returns (ctx, used_rows): a device context holding
+lambda * scaleY(Y)[used_rows, :] (never materialised on the host) for a factorization of rank H, and the kept rows
+(1-based).  Create parameters for L = length(used_rows) and run them with `vbmf_on!(ctx, params, niter; ...)`.
+"""
+function preprocess_device(Y::Array{Float64,2}, lambda::Float64, H::Int)
+    L, M = size(Y)
+    plan = Ref{Ptr{Cvoid}}(C_NULL); nused = Ref{Int64}(0)
+    rc = ccall((:vbmf_preprocess_open, libvbmf), Cint, (Ref{Ptr{Cvoid}}, Cint, Ptr{Float64}, Int64, Int64, Int64, Ref{Int64}),
+               plan, 0, Y, L, M, L, nused)
+    rc == 0 || error(unsafe_string(ccall((:vbmf_last_error, libvbmf), Cstring, (Ptr{Cvoid},), C_NULL)))
+    rows = Array{Int64}(undef, nused[])
+    ccall((:vbmf_preprocess_rows, libvbmf), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}), plan[], rows, C_NULL, C_NULL)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    ydt = get(ENV, "VBMF_HIP_Y", "bf16") == "f32" ? VBMF_Y_F32 : VBMF_Y_BF16
+    opts = Ref(VbmfOpts(Int32(sizeof(VbmfOpts)), 0, ydt, 0, 0, 0xffffffff, 1, 0, 0, 0, 0, 0))
+    rc = ccall((:vbmf_create, libvbmf), Cint, (Ref{Ptr{Cvoid}}, Int64, Int64, Int64, Ref{VbmfOpts}), h, nused[], M, H, opts)
+    rc == 0 || error(unsafe_string(ccall((:vbmf_last_error, libvbmf), Cstring, (Ptr{Cvoid},), C_NULL)))
+    chk(h[], ccall((:vbmf_set_Y_preprocessed, libvbmf), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Float64), h[], plan[], lambda))
+    ccall((:vbmf_preprocess_close, libvbmf), Cint, (Ptr{Cvoid},), plan[])
+    c = Ctx(h[], Y)
+    finalizer(x -> ccall((:vbmf_destroy, libvbmf), Cint, (Ptr{Cvoid},), x.h), c)
+    return c, rows .+ 1
+end
+
+"vbmf! on a context that already holds its matrix (preprocess_device): same loop as vbmf!"
+function vbmf_on!(c::Ctx, params::vbmf_parameters, niter::Int; eps::Float64 = 1e-6, est_covs::Bool = false, est_var::Bool = false)
+    push!(c, params)
+    iters = Ref{Int64}(0); d = Ref{Float64}(0.0)
+    chk(c.h, ccall((:vbmf_run, libvbmf), Cint,
+        (Ptr{Cvoid}, Int64, Float64, Cint, Cint, Ref{Int64}, Ref{Float64}, Ptr{Float64}),
+        c.h, niter, eps, est_covs, est_var, iters, d, C_NULL))
+    pull!(c, params)
     return params
 end
 
