@@ -344,3 +344,27 @@ def test_rank_above_128_slow_path(pkg):
     _, n, d = O.vbmf_(Ys, po, 2, eps=0.0, est_covs=True, est_var=True)
     compare("bf16x2 900x640 H200 run2", pg, po, {k: 6 * v for k, v in tol.items()})
     assert abs(pg._last_run[1] - d) <= 2e-2 * d
+
+
+def test_logged_trajectory_against_the_reference_record(pkg, golden_dir, tmp_path):
+    """vbmf!(...; logdir=...) (src/vbmf.jl:181-184,205-207,224-228): run the reference's recorded experiment on the
+    device with per-sweep logging, read the log back with the data_manip twin and compare EVERY slice with the
+    reference's own log.jld (tests/golden/vbmf_test.npz, 100 sweeps, est_covs = est_var = true)."""
+    z = np.load(os.path.join(golden_dir, "vbmf_test.npz"))
+    ref = {k: np.moveaxis(z[k], 0, -1) for k in z.files if k != "Y"}          # time last, as Julia sees it
+    Y = np.ascontiguousarray(z["Y"])
+    p = pkg.vbmf_parameters()
+    pkg.extract_params_(ref, 0, p)
+    p.labels = np.zeros(0, dtype=np.int64)
+    p.YHat = None
+    pkg.set_defaults(y_dtype=pkg.VBMF_Y_F32, factor_dtype=pkg.VBMF_FACTOR_AUTO)
+    pkg.vbmf_(Y, p, 100, eps=0.0, est_covs=True, est_var=True, logdir=str(tmp_path), desc="fixture")
+    log, Yl, _ = pkg.load_log(os.path.join(str(tmp_path), "fixture"))
+    assert np.array_equal(Yl, Y) and log["sigma2"].shape == (101,) and log["AHat"].shape == (20, 2, 101)
+    worst = {}
+    for f in ("AHat", "BHat", "SigmaA", "SigmaB", "CA", "CB", "invCA", "invCB"):
+        errs = [relF(log[f][..., t], ref[f][..., t]) for t in range(101)]
+        worst[f] = max(errs)
+    worst["sigma2"] = float(np.max(np.abs(log["sigma2"] - ref["sigma2"]) / ref["sigma2"]))
+    report("logged trajectory vs the reference's recorded log, worst slice: " + " ".join(f"{k}={v:.2e}" for k, v in worst.items()))
+    assert max(worst.values()) < 2e-3, worst

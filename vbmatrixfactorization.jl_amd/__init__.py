@@ -31,6 +31,7 @@ from typing import Optional
 import numpy as np
 
 from . import capi, dist
+from .data_manip import create_log, update_log_, save_log, load_log, extract_params_
 from .capi import PreprocessPlan
 from .capi import (Context, VbmfError, VBMF_Y_F32, VBMF_Y_BF16, VBMF_FACTOR_AUTO, VBMF_FACTOR_BF16,
                    VBMF_FACTOR_BF16X2, VBMF_VARIANT_SPARSE_DIAG, STEP_A, STEP_B, STEP_CA, STEP_CB, STEP_SIGMA2,
@@ -253,21 +254,38 @@ def elbo(Y, params):
     return s.ctx.elbo()
 
 
-def vbmf_(Y, params, niter, eps=1e-6, est_covs=False, est_var=False, logdir="", desc="", verb=False):
-    """vbmf! -- src/vbmf.jl:175-231.  `params` is modified in place and returned."""
-    if logdir != "":
-        raise NotImplementedError("per-iteration JLD logging (src/data_manip.jl) is outside the accelerated path")
+def vbmf_(Y, params, niter, eps=1e-6, est_covs=False, est_var=False, logdir="", desc="", verb=False, log_every=1):
+    """vbmf! -- src/vbmf.jl:175-231.  `params` is modified in place and returned.
+    logdir != "": the trajectory is logged like the reference does (slice 0 = the initial state, then one slice per
+    sweep, src/vbmf.jl:181-184,205-207) and saved under logdir/desc (data_manip.py); that pulls the state off the
+    device every `log_every` sweeps (an extension; 1 = the reference's behaviour), so it is a debugging mode."""
     _check(Y, params)
     s = _session_for(Y, params.H)
     s.push(params)
-    iters, d, _ = s.run(int(niter), eps=eps, est_covs=est_covs, est_var=est_var)
-    s.pull(params)
+    if logdir != "":
+        logVar = create_log(params)
+        i, d, iters = 1, eps + 1.0, 0
+        while i <= niter and d > eps:                          # src/vbmf.jl:193 on the host, one device call per chunk
+            k = int(min(max(1, log_every), niter - i + 1))
+            done, d, _ = s.run(k, eps=eps, est_covs=est_covs, est_var=est_var)
+            s.pull(params)
+            update_log_(logVar, params)
+            iters += done
+            i += done
+            if done < k:
+                break
+    else:
+        iters, d, _ = s.run(int(niter), eps=eps, est_covs=est_covs, est_var=est_var)
+        s.pull(params)
     if params.L * params.M <= YHAT_AUTO_LIMIT:
         params.YHat = s.ctx.YHat()                             # :217
     else:
         params.YHat = None
     if verb:
         print(f"Factorization finished after {iters} iterations, eps = {d}")   # :221
+    if logdir != "":
+        print(f"Saving outputs and inputs under {logdir}/")                    # :226
+        save_log(logVar, Y, {}, logdir, desc=desc)
     params._last_run = (iters, d)
     return params
 
@@ -422,19 +440,33 @@ def sparse_updateSigma_(Y, params, diag_var=False):
     _sone(Y, params, SSTEP_SIGMA)
 
 
-def vbmf_sparse_(Y, params, niter, eps=1e-6, diag_var=False, full_cov=False, logdir="", desc="", verb=False, est_cb=True):
-    """vbmf_sparse! -- src/vbmf_sparse.jl:344-410.  Returns d (like the reference)."""
+def vbmf_sparse_(Y, params, niter, eps=1e-6, diag_var=False, full_cov=False, logdir="", desc="", verb=False, est_cb=True,
+                 log_every=1):
+    """vbmf_sparse! -- src/vbmf_sparse.jl:344-410.  Returns d (like the reference).  logdir: see vbmf_."""
     if full_cov or diag_var:
         raise NotImplementedError("only full_cov=false, diag_var=false is built (SURVEY.md section 2)")
-    if logdir != "":
-        raise NotImplementedError("per-iteration JLD logging is outside the accelerated path")
     c = _sparse_ctx(Y, params)
     _spush(c, params)
-    iters, d, _ = c.sparse_run(int(niter), eps=eps, est_cb=est_cb)
-    _spull(c, params)
+    if logdir != "":
+        logVar = create_log(params)
+        i, d, iters = 1, eps + 1.0, 0
+        while i <= niter and d > eps:
+            k = int(min(max(1, log_every), niter - i + 1))
+            done, d, _ = c.sparse_run(k, eps=eps, est_cb=est_cb)
+            _spull(c, params)
+            update_log_(logVar, params)
+            iters += done
+            i += done
+            if done < k:
+                break
+    else:
+        iters, d, _ = c.sparse_run(int(niter), eps=eps, est_cb=est_cb)
+        _spull(c, params)
     params.YHat = params.BHat @ params.AHat.T if params.L * params.M <= YHAT_AUTO_LIMIT else None   # :396 (host, small only)
     if verb:
         print(f"Factorization finished after {iters} iterations, eps = {d}")
+    if logdir != "":
+        save_log(logVar, Y, {}, logdir, desc=desc)
     params._last_run = (iters, d)
     return d
 
