@@ -49,6 +49,7 @@ typedef enum {
 
 #define VBMF_VARIANT_BASIC 0        /* src/vbmf.jl */
 #define VBMF_VARIANT_SPARSE_DIAG 1  /* src/vbmf_sparse.jl, full_cov=false, diag_var=false */
+#define VBMF_VARIANT_SPARSE_DIAGVAR 2 /* src/vbmf_sparse.jl, full_cov=false, diag_var=true: one noise precision per row */
 
 /* reference_compat bits (default: all set = behave like the reference) */
 #define VBMF_COMPAT_SPECTRAL_DELTA 1u  /* d uses operator 2-norms (src/util.jl:27-29, Julia 0.5 norm) */
@@ -151,6 +152,12 @@ int vbmf_sparse_set_state(vbmf_ctx* ctx, const double* ATVecHat, const double* d
 int vbmf_sparse_get_state(vbmf_ctx* ctx, double* ATVecHat, double* diagSigmaATVec, double* CA, double* beta,
                           double* SigmaA_diag, double* BHat, int64_t ldB, double* SigmaB, double* CB,
                           double* delta, double* sigmaHat, double* zeta);
+/* Heteroscedastic rows (VBMF_VARIANT_SPARSE_DIAGVAR; src/vbmf_sparse.jl:207-212,229-230,256-261,308-315): the same
+ * vbmf_sparse_* entry points then run the diag_var=true updates; the row-noise state travels separately:
+ * sigmaVecHat, zetaVec (length L) and the common Gamma shape etaVec = eta0 + M/2 (:145-147).  set: after
+ * vbmf_sparse_set_state (whose sigmaHat/zeta are ignored); get_state's sigmaHat is mean(sigmaVecHat). */
+int vbmf_sparse_set_noise_rows(vbmf_ctx* ctx, const double* sigmaVecHat, const double* zetaVec, double etaVec);
+int vbmf_sparse_get_noise_rows(vbmf_ctx* ctx, double* sigmaVecHat, double* zetaVec);
 /* vbls! on the sparse model (examples/mil_util.jl:187-190): niter x (updateA!, updateCA!, updateSigma!), B frozen */
 int vbmf_sparse_run_fixed_basis(vbmf_ctx* ctx, int64_t niter);
 int vbmf_sparse_step(vbmf_ctx* ctx, int which);            /* reference order A, B, CA, CB, SIGMA (:369-376) */

@@ -299,12 +299,12 @@ def copy_vbmf_params(Y, old, rng=None):
     return p
 
 
-def vbls_sparse_(Y, p, niter, reference_compat=True):
-    """examples/mil_util.jl:187-190, vbmf_sparse_parameters branch (full_cov=false, diag_var=false)."""
+def vbls_sparse_(Y, p, niter, reference_compat=True, diag_var=False):
+    """examples/mil_util.jl:187-190, vbmf_sparse_parameters branch (full_cov=false)."""
     for _ in range(niter):
-        sparse_updateA(Y, p, full_cov=False, reference_compat=reference_compat)
+        sparse_updateA(Y, p, full_cov=False, reference_compat=reference_compat, diag_var=diag_var)
         sparse_updateCA(p)
-        sparse_updateSigma(Y, p)
+        sparse_updateSigma(Y, p, diag_var=diag_var)
     return p.AHat
 
 
@@ -400,10 +400,20 @@ def spread_v(v, M, reference_compat=True):
     return np.tile(v, M)
 
 
-def sparse_updateA(Y, p, full_cov=False, reference_compat=True):
-    """src/vbmf_sparse.jl:176-247, diag_var=false branches."""
+def sparse_updateA(Y, p, full_cov=False, reference_compat=True, diag_var=False):
+    """src/vbmf_sparse.jl:176-247 (full_cov with diag_var=false only; the diagonal branch with either noise model)."""
     L, M, H = p.L, p.M, p.H
-    if full_cov:                                                    # :178-202
+    if full_cov and diag_var:
+        raise NotImplementedError("full_cov with diag_var is outside the restated path")
+    if not full_cov and diag_var:                                   # :207-212, 229-230 (heteroscedastic rows)
+        sB = p.BHat * p.sigmaVecHat[:, None]
+        v = np.sum(sB * sB, axis=0) + L * np.mean(p.sigmaVecHat) * np.diag(p.SigmaB)   # :211 (sigma enters squared)
+        prec = spread_v(v, M, reference_compat) + p.CA
+        p.diagSigmaATVec = 1.0 / prec
+        BtY = sB.T @ Y                                              # B' diag(sigmaVec) Y
+        p.ATVecHat = p.diagSigmaATVec * BtY.T.reshape(M * H)        # :230 (no sigmaHat factor)
+        p.SigmaA = np.diag(p.diagSigmaATVec.reshape(M, H).sum(axis=0))
+    elif full_cov:                                                  # :178-202
         K = p.sigmaHat * (p.BHat.T @ p.BHat + L * p.SigmaB)
         p.invSigmaATVec = np.kron(np.eye(M), K) + np.diag(p.CA)
         p.SigmaATVec = np.linalg.inv(p.invSigmaATVec)
@@ -425,8 +435,12 @@ def sparse_updateA(Y, p, full_cov=False, reference_compat=True):
     p.ATVecHat = p.AHat.reshape(M * H).copy()                       # :246
 
 
-def sparse_updateB(Y, p):
-    """src/vbmf_sparse.jl:263-266."""
+def sparse_updateB(Y, p, diag_var=False):
+    """src/vbmf_sparse.jl:254-268."""
+    if diag_var:                                                    # :256-261
+        p.SigmaB = np.linalg.inv(np.diag(p.CB) + np.mean(p.sigmaVecHat) * (p.AHat.T @ p.AHat + p.SigmaA))
+        p.BHat = p.sigmaVecHat[:, None] * ((Y @ p.AHat) @ p.SigmaB)
+        return
     p.SigmaB = np.linalg.inv(np.diag(p.CB) + p.sigmaHat * (p.AHat.T @ p.AHat + p.SigmaA))
     p.BHat = p.sigmaHat * ((Y @ p.AHat) @ p.SigmaB)
 
@@ -443,25 +457,32 @@ def sparse_updateCB(p):
     p.CB = p.gamma / p.delta
 
 
-def sparse_updateSigma(Y, p):
-    """src/vbmf_sparse.jl:317-321."""
+def sparse_updateSigma(Y, p, diag_var=False):
+    """src/vbmf_sparse.jl:308-321."""
+    if diag_var:                                                    # :309-315, row by row
+        G = p.AHat.T @ p.AHat + p.SigmaA
+        Q = Y @ p.AHat
+        quad = np.einsum("lh,hk,lk->l", p.BHat, G, p.BHat) + np.sum(G * p.SigmaB)    # tr(G (b b' + SigmaB))
+        p.zetaVec = p.zeta0 + 0.5 * np.sum(Y * Y, axis=1) - np.sum(Q * p.BHat, axis=1) + 0.5 * quad
+        p.sigmaVecHat = p.etaVec / p.zetaVec
+        return
     p.zeta = (p.zeta0 + 0.5 * p.trYTY - traceXTY(p.BHat, Y @ p.AHat)
               + 0.5 * traceXTY(p.AHat.T @ p.AHat + p.SigmaA, p.BHat.T @ p.BHat + p.L * p.SigmaB))
     p.sigmaHat = p.eta / p.zeta
 
 
-def vbmf_sparse_(Y, p, niter, eps=1e-6, full_cov=False, est_cb=True, reference_compat=True, trace=None):
-    """vbmf_sparse! -- src/vbmf_sparse.jl:344-410 (diag_var=false).  Returns (d, iterations)."""
+def vbmf_sparse_(Y, p, niter, eps=1e-6, full_cov=False, est_cb=True, reference_compat=True, trace=None, diag_var=False):
+    """vbmf_sparse! -- src/vbmf_sparse.jl:344-410.  Returns (d, iterations)."""
     old = p.BHat.copy()
     d = eps + 1.0
     i = 1
     while i <= niter and d > eps:
-        sparse_updateA(Y, p, full_cov=full_cov, reference_compat=reference_compat)
-        sparse_updateB(Y, p)
+        sparse_updateA(Y, p, full_cov=full_cov, reference_compat=reference_compat, diag_var=diag_var)
+        sparse_updateB(Y, p, diag_var=diag_var)
         sparse_updateCA(p)
         if est_cb:
             sparse_updateCB(p)
-        sparse_updateSigma(Y, p)
+        sparse_updateSigma(Y, p, diag_var=diag_var)
         d = delta(p.BHat, old)
         old = p.BHat.copy()
         if trace is not None:

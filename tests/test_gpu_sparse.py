@@ -141,3 +141,78 @@ def test_sparse_termination(pkg, golden_dir):
     report(f"sparse termination: oracle n={n} d={d_ref:.3e}; gpu n={pg._last_run[0]} d={d_gpu:.3e}")
     assert 3 < n < 400 and abs(pg._last_run[0] - n) <= 2 and d_gpu <= 1e-3
     _cmp("termination", pg, po, 5e-3)
+
+
+# ---- heteroscedastic rows: diag_var = true ------------------------------------
+def _mk_hetero(L, M, H, seed, **kw):
+    """toy data whose rows have different noise levels (what diag_var models)."""
+    rng = np.random.default_rng(seed)
+    Y, A, B = O.toy_matrix(L, M, H, 0.0, rng)
+    Y = (B * np.linspace(1.0, 2.5, H)) @ A.T + rng.uniform(0.02, 0.4, (L, 1)) * rng.standard_normal((L, M))
+    po = O.vbmf_sparse_init(Y, H, ca=1.0, cb=1.0, sigma=1.0, rng=np.random.default_rng(seed + 1), full_cov=False,
+                            materialize_yhat=False, **kw)
+    return Y, po
+
+
+def _to_pkg_hetero(pkg, po):
+    p = _to_pkg(pkg, po)
+    p.sigmaVecHat, p.etaVec, p.zetaVec = po.sigmaVecHat.copy(), po.etaVec.copy(), po.zetaVec.copy()
+    return p
+
+
+HFIELDS = FIELDS + ("sigmaVecHat", "zetaVec")
+
+
+def _cmp_h(tag, pg, po, tol):
+    errs = {f: relF(getattr(pg, f), getattr(po, f)) for f in HFIELDS}
+    report(f"sparse diag_var {tag}: " + " ".join(f"{k}={v:.2e}" for k, v in errs.items()))
+    bad = {k: v for k, v in errs.items() if not v <= tol}
+    assert not bad, (tag, bad)
+
+
+@pytest.mark.parametrize("L,M,H", [(10, 20, 2), (300, 170, 5), (500, 260, 40)])
+def test_hetero_each_update_f32(pkg, L, M, H):
+    """updateA!/updateB!/updateCA!/updateCB!/updateSigma! with diag_var=true (src/vbmf_sparse.jl:207-212,229-230,256-261,
+    308-315), each from the oracle's state after a few heteroscedastic sweeps.  PARITY UNPINNED (no recorded run)."""
+    Y, po = _mk_hetero(L, M, H, 300 + L)
+    Yf = Y.astype(np.float32).astype(np.float64)
+    po.trYTY = float(np.sum(Yf * Yf))
+    O.vbmf_sparse_(Yf, po, 3, eps=0.0, full_cov=False, diag_var=True)
+    pkg.set_defaults(y_dtype=pkg.VBMF_Y_F32, factor_dtype=pkg.VBMF_FACTOR_AUTO)
+    import copy
+    for name, fo, fg in [("A", lambda q: O.sparse_updateA(Yf, q, diag_var=True), lambda q: pkg.sparse_updateA_(Yf, q, diag_var=True)),
+                         ("B", lambda q: O.sparse_updateB(Yf, q, diag_var=True), lambda q: pkg.sparse_updateB_(Yf, q, diag_var=True)),
+                         ("Sigma", lambda q: O.sparse_updateSigma(Yf, q, diag_var=True), lambda q: pkg.sparse_updateSigma_(Yf, q, diag_var=True))]:
+        qo = copy.deepcopy(po)
+        qg = _to_pkg_hetero(pkg, po)
+        fo(qo); fg(qg)
+        _cmp_h(f"update {name} {L}x{M} H={H}", qg, qo, 2e-5)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x2"])
+def test_hetero_run(pkg, mode):
+    L, M, H = 600, 380, 6
+    Y, po = _mk_hetero(L, M, H, 77, H1=2, labels=[3, 50, 200])
+    ydt = pkg.VBMF_Y_F32 if mode == "f32" else pkg.VBMF_Y_BF16
+    with pkg.capi.Context(L, M, H, y_dtype=ydt) as c:
+        c.set_Y(Y)
+        Ys = np.ascontiguousarray(c.get_Y())
+    po.trYTY = float(np.sum(Ys * Ys))
+    pkg.set_defaults(y_dtype=ydt, factor_dtype=pkg.VBMF_FACTOR_AUTO)
+    pg = _to_pkg_hetero(pkg, po)
+    d_gpu = pkg.vbmf_sparse_(Ys, pg, 8, eps=0.0, diag_var=True)
+    d_ref, n = O.vbmf_sparse_(Ys, po, 8, eps=0.0, full_cov=False, diag_var=True)
+    _cmp_h(f"run8 {mode}", pg, po, 2e-3 if mode == "f32" else 5e-3)
+    assert pg._last_run[0] == 8 and abs(d_gpu - d_ref) <= 2e-2 * d_ref + 2e-6
+    # the rows' precisions track the rows' noise levels (what the model is for)
+    assert np.corrcoef(np.log(pg.sigmaVecHat), np.log(po.sigmaVecHat))[0, 1] > 0.999
+    # fixed-basis inference with heteroscedastic rows (vbls!, diag_var = true): both passes every iteration
+    qo = O.copy_vbmf_params(Ys, po, rng=np.random.default_rng(4))
+    qg = pkg.copy_vbmf_params(Ys, pg, rng=np.random.default_rng(4))
+    qo.BHat, qo.SigmaB, qo.CB = po.BHat.copy(), po.SigmaB.copy(), po.CB.copy()
+    qg.BHat, qg.SigmaB, qg.CB = po.BHat.copy(), po.SigmaB.copy(), po.CB.copy()
+    pkg.vbls_(Ys, qg, 5, diag_var=True)
+    O.vbls_sparse_(Ys, qo, 5, diag_var=True)
+    errs = {f: relF(getattr(qg, f), getattr(qo, f)) for f in ("ATVecHat", "diagSigmaATVec", "CA", "sigmaVecHat")}
+    report(f"sparse diag_var vbls5 {mode}: " + " ".join(f"{k}={v:.2e}" for k, v in errs.items()))
+    assert max(errs.values()) < (2e-3 if mode == "f32" else 5e-3), errs

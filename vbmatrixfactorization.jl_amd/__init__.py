@@ -34,7 +34,7 @@ from . import capi, dist
 from .data_manip import create_log, update_log_, save_log, load_log, extract_params_
 from .capi import PreprocessPlan
 from .capi import (Context, VbmfError, VBMF_Y_F32, VBMF_Y_BF16, VBMF_FACTOR_AUTO, VBMF_FACTOR_BF16,
-                   VBMF_FACTOR_BF16X2, VBMF_VARIANT_SPARSE_DIAG, STEP_A, STEP_B, STEP_CA, STEP_CB, STEP_SIGMA2,
+                   VBMF_FACTOR_BF16X2, VBMF_VARIANT_SPARSE_DIAG, VBMF_VARIANT_SPARSE_DIAGVAR, STEP_A, STEP_B, STEP_CA, STEP_CB, STEP_SIGMA2,
                    SSTEP_A, SSTEP_B, SSTEP_CA, SSTEP_CB, SSTEP_SIGMA)
 
 __all__ = ["vbmf_parameters", "vbmf_init", "vbmf", "vbmf_", "copy", "updateA_", "updateB_", "updateCA_",
@@ -365,6 +365,7 @@ def vbmf_sparse_init(Y, H, ca=1.0, alpha0=1e-10, beta0=1e-10, cb=1.0, gamma0=1e-
     p.CB = cb * np.ones(H)
     p.gamma0, p.delta0, p.gamma, p.delta = gamma0, delta0, gamma0 + L / 2, delta0 * np.ones(H)
     p.sigmaHat, p.eta0, p.zeta0, p.eta, p.zeta = float(sigma), eta0, zeta0, eta0 + L * M / 2, zeta0
+    p.sigmaVecHat, p.etaVec, p.zetaVec = sigma * np.ones(L), (eta0 + M / 2) * np.ones(L), zeta0 * np.ones(L)   # :145-147
     p.YHat = p.BHat @ p.AHat.T if L * M <= YHAT_AUTO_LIMIT else None
     p.trYTY = float(np.sum(Y * Y))
     return p
@@ -373,54 +374,58 @@ def vbmf_sparse_init(Y, H, ca=1.0, alpha0=1e-10, beta0=1e-10, cb=1.0, gamma0=1e-
 _sparse_sessions = {}
 
 
-def _sparse_ctx(Y, p):
+def _sparse_ctx(Y, p, diag_var=False):
     Y = np.asarray(Y, dtype=np.float64)
-    key = (id(Y), Y.shape, Y.__array_interface__["data"][0], int(p.H), tuple(sorted(_defaults.items())))
+    key = (id(Y), Y.shape, Y.__array_interface__["data"][0], int(p.H), bool(diag_var), tuple(sorted(_defaults.items())))
     ent = _sparse_sessions.get(key)
     if ent is not None and ent[1]() is Y:
         return ent[0]
     for k in list(_sparse_sessions):
         _sparse_sessions.pop(k)[0].close()
-    c = Context(Y.shape[0], Y.shape[1], p.H, variant=VBMF_VARIANT_SPARSE_DIAG, **_defaults)
+    c = Context(Y.shape[0], Y.shape[1], p.H, variant=VBMF_VARIANT_SPARSE_DIAGVAR if diag_var else VBMF_VARIANT_SPARSE_DIAG,
+                **_defaults)
     c.set_Y(Y)
     _sparse_sessions[key] = (c, weakref.ref(Y))
     return c
 
 
-def _spush(c, p):
+def _spush(c, p, diag_var=False):
     hyper = dict(alpha0=p.alpha0, beta0=p.beta0, gamma0=p.gamma0, delta0=p.delta0, eta0=p.eta0, zeta0=p.zeta0)
     c.sparse_set_state(p.ATVecHat, p.diagSigmaATVec, p.CA, p.beta, p.BHat, p.SigmaB, p.CB, p.delta, p.sigmaHat,
                        p.zeta, hyper, labels0=_labels0(p), H1=p.H1)
+    if diag_var:
+        c.sparse_set_noise_rows(p.sigmaVecHat, p.zetaVec, float(np.asarray(p.etaVec).reshape(-1)[0]))
 
 
-def _spull(c, p):
+def _spull(c, p, diag_var=False):
     s = c.sparse_get_state()
+    if diag_var:
+        p.sigmaVecHat, p.zetaVec = c.sparse_get_noise_rows()
     p.ATVecHat, p.diagSigmaATVec, p.CA, p.beta = s["ATVecHat"], s["diagSigmaATVec"], s["CA"], s["beta"]
     p.AHat = p.ATVecHat.reshape(p.M, p.H).copy()
     p.SigmaA = np.diag(s["SigmaA_diag"])
     p.BHat, p.SigmaB, p.CB, p.delta = s["BHat"], s["SigmaB"], s["CB"], s["delta"]
-    p.sigmaHat, p.zeta = s["sigmaHat"], s["zeta"]
+    if not diag_var:
+        p.sigmaHat, p.zeta = s["sigmaHat"], s["zeta"]
 
 
-def _sone(Y, p, which):
-    c = _sparse_ctx(Y, p)
-    _spush(c, p)
+def _sone(Y, p, which, diag_var=False):
+    c = _sparse_ctx(Y, p, diag_var)
+    _spush(c, p, diag_var)
     c.sparse_step(which)
-    _spull(c, p)
+    _spull(c, p, diag_var)
 
 
 def sparse_updateA_(Y, params, full_cov=False, diag_var=False):
     """updateA! -- src/vbmf_sparse.jl:176-247 (diagonal branch only)."""
-    if full_cov or diag_var:
-        raise NotImplementedError("only full_cov=false, diag_var=false is built (SURVEY.md section 2)")
-    _sone(Y, params, SSTEP_A)
+    if full_cov:
+        raise NotImplementedError("only full_cov=false is built (SURVEY.md section 2)")
+    _sone(Y, params, SSTEP_A, diag_var)
 
 
 def sparse_updateB_(Y, params, diag_var=False):
     """updateB! -- src/vbmf_sparse.jl:254-268."""
-    if diag_var:
-        raise NotImplementedError("diag_var=true is out of scope")
-    _sone(Y, params, SSTEP_B)
+    _sone(Y, params, SSTEP_B, diag_var)
 
 
 def sparse_updateCA_(params, Y=None):
@@ -434,26 +439,24 @@ def sparse_updateCB_(params, Y=None):
 
 
 def sparse_updateSigma_(Y, params, diag_var=False):
-    """updateSigma! -- src/vbmf_sparse.jl:307-322 (homoscedastic)."""
-    if diag_var:
-        raise NotImplementedError("diag_var=true is out of scope")
-    _sone(Y, params, SSTEP_SIGMA)
+    """updateSigma! -- src/vbmf_sparse.jl:307-322 (diag_var: one Gamma posterior per row, :308-315)."""
+    _sone(Y, params, SSTEP_SIGMA, diag_var)
 
 
 def vbmf_sparse_(Y, params, niter, eps=1e-6, diag_var=False, full_cov=False, logdir="", desc="", verb=False, est_cb=True,
                  log_every=1):
     """vbmf_sparse! -- src/vbmf_sparse.jl:344-410.  Returns d (like the reference).  logdir: see vbmf_."""
-    if full_cov or diag_var:
-        raise NotImplementedError("only full_cov=false, diag_var=false is built (SURVEY.md section 2)")
-    c = _sparse_ctx(Y, params)
-    _spush(c, params)
+    if full_cov:
+        raise NotImplementedError("only full_cov=false is built (SURVEY.md section 2)")
+    c = _sparse_ctx(Y, params, diag_var)
+    _spush(c, params, diag_var)
     if logdir != "":
         logVar = create_log(params)
         i, d, iters = 1, eps + 1.0, 0
         while i <= niter and d > eps:
             k = int(min(max(1, log_every), niter - i + 1))
             done, d, _ = c.sparse_run(k, eps=eps, est_cb=est_cb)
-            _spull(c, params)
+            _spull(c, params, diag_var)
             update_log_(logVar, params)
             iters += done
             i += done
@@ -461,7 +464,7 @@ def vbmf_sparse_(Y, params, niter, eps=1e-6, diag_var=False, full_cov=False, log
                 break
     else:
         iters, d, _ = c.sparse_run(int(niter), eps=eps, est_cb=est_cb)
-        _spull(c, params)
+        _spull(c, params, diag_var)
     params.YHat = params.BHat @ params.AHat.T if params.L * params.M <= YHAT_AUTO_LIMIT else None   # :396 (host, small only)
     if verb:
         print(f"Factorization finished after {iters} iterations, eps = {d}")
@@ -495,13 +498,13 @@ def vbls_(Y, params, niter, diag_var=False, full_cov=False):
     """vbls! -- examples/mil_util.jl:179-203: solves Y = B A' + E for A with B (and SigmaB, CB) fixed: niter x
     (updateA!, updateCA!, updateSigma2! / updateSigma!), then updateYHat!; returns params.AHat.
     On the device Y'B is formed once per call (B is fixed), so the call reads Y once, not 2 x niter times."""
-    if full_cov or diag_var:
-        raise NotImplementedError("only full_cov=false, diag_var=false is built (SURVEY.md section 2)")
+    if full_cov:
+        raise NotImplementedError("only full_cov=false is built (SURVEY.md section 2)")
     if isinstance(params, vbmf_sparse_parameters):
-        c = _sparse_ctx(Y, params)
-        _spush(c, params)
+        c = _sparse_ctx(Y, params, diag_var)
+        _spush(c, params, diag_var)
         c.sparse_run_fixed_basis(int(niter))
-        _spull(c, params)
+        _spull(c, params, diag_var)
         params.YHat = params.BHat @ params.AHat.T if params.L * params.M <= YHAT_AUTO_LIMIT else None
         return params.AHat
     _check(Y, params)

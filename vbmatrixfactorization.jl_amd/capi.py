@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libvbmf_hip.so")
 
 VBMF_Y_F32, VBMF_Y_BF16 = 0, 1
 VBMF_FACTOR_AUTO, VBMF_FACTOR_BF16, VBMF_FACTOR_BF16X2 = 0, 1, 2
-VBMF_VARIANT_BASIC, VBMF_VARIANT_SPARSE_DIAG = 0, 1
+VBMF_VARIANT_BASIC, VBMF_VARIANT_SPARSE_DIAG, VBMF_VARIANT_SPARSE_DIAGVAR = 0, 1, 2
 VBMF_COMPAT_SPECTRAL_DELTA, VBMF_COMPAT_SPARSE_REPEAT, VBMF_COMPAT_DEFAULT = 1, 2, 0xFFFFFFFF
 STEP_A, STEP_B, STEP_CA, STEP_CB, STEP_SIGMA2 = 1, 2, 4, 8, 16
 UNIQUE_ID_BYTES = 128
@@ -26,7 +26,7 @@ SYMBOLS = [
     "vbmf_elbo", "vbmf_comm_unique_id", "vbmf_comm_init", "vbmf_comm_set_transport", "vbmf_profile_enable", "vbmf_profile_read",
     "vbmf_pass_bytes", "vbmf_device_sync", "vbmf_debug_peek", "vbmf_debug_time_pass",
     "vbmf_sparse_set_state", "vbmf_sparse_get_state", "vbmf_sparse_step", "vbmf_sparse_run", "vbmf_sparse_run_fixed_basis",
-    "vbmf_sparse_lower_bound", "vbmf_preprocess_open", "vbmf_preprocess_rows", "vbmf_set_Y_preprocessed",
+    "vbmf_sparse_lower_bound", "vbmf_sparse_set_noise_rows", "vbmf_sparse_get_noise_rows", "vbmf_preprocess_open", "vbmf_preprocess_rows", "vbmf_set_Y_preprocessed",
     "vbmf_preprocess_close",
 ]
 SSTEP_A, SSTEP_B, SSTEP_CA, SSTEP_CB, SSTEP_SIGMA = 1, 2, 4, 8, 16
@@ -112,6 +112,8 @@ def lib():
     L.vbmf_sparse_step.argtypes = [vp, i32]
     L.vbmf_sparse_run.argtypes = [vp, i64, C.c_double, i32, C.POINTER(i64), dp, dp]
     L.vbmf_sparse_lower_bound.argtypes = [vp, i32, dp]
+    L.vbmf_sparse_set_noise_rows.argtypes = [vp, dp, dp, C.c_double]
+    L.vbmf_sparse_get_noise_rows.argtypes = [vp, dp, dp]
     L.vbmf_preprocess_open.argtypes = [C.POINTER(vp), i32, dp, i64, i64, i64, C.POINTER(i64)]
     L.vbmf_preprocess_rows.argtypes = [vp, C.POINTER(i64), dp, dp]
     L.vbmf_set_Y_preprocessed.argtypes = [vp, vp, C.c_double]
@@ -320,6 +322,17 @@ class Context:
         tr = np.zeros((max(niter, 1), 4)) if want_trace else None
         self._chk(self._lib.vbmf_sparse_run(self._h, niter, eps, int(est_cb), C.byref(it), C.byref(d), _dptr(tr)))
         return it.value, d.value, (tr[:it.value] if want_trace else None)
+
+    def sparse_set_noise_rows(self, sigmaVecHat, zetaVec, etaVec):
+        s = np.ascontiguousarray(sigmaVecHat, dtype=np.float64); z = np.ascontiguousarray(zetaVec, dtype=np.float64)
+        if s.shape != (self.L,) or z.shape != (self.L,):
+            raise ValueError("sigmaVecHat and zetaVec must have length L")
+        self._chk(self._lib.vbmf_sparse_set_noise_rows(self._h, _dptr(s), _dptr(z), float(etaVec)))
+
+    def sparse_get_noise_rows(self):
+        s, z = np.empty(self.L), np.empty(self.L)
+        self._chk(self._lib.vbmf_sparse_get_noise_rows(self._h, _dptr(s), _dptr(z)))
+        return s, z
 
     def sparse_lower_bound(self, clamp=True):
         v = C.c_double()

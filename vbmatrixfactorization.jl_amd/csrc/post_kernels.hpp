@@ -287,9 +287,13 @@ __global__ __launch_bounds__(1024) void pair_slab_reduce_kernel(const float* __r
     }
 }
 
+// rowscale != nullptr: the value tiled (and, with writeback, stored back) is rowscale[x] * Fac[x][h]
 template <int MODE, int NH>
-__global__ __launch_bounds__(256) void retile_kernel(float* __restrict__ Fac, uint4* __restrict__ Ft, int XT) {
+__global__ __launch_bounds__(256) void retile_kernel(float* __restrict__ Fac, uint4* __restrict__ Ft, int XT,
+                                                     const float* __restrict__ rowscale, int writeback,
+                                                     const int* __restrict__ stop) {
     constexpr int Hp = NH * 32;
+    if (stop && *stop) return;
     const int lane = threadIdx.x & 63;
     const int xt = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (xt >= XT) return;
@@ -299,9 +303,12 @@ __global__ __launch_bounds__(256) void retile_kernel(float* __restrict__ Fac, ui
     for (int h = 0; h < NH; ++h) {
         f32x16 v;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = Fac[(x0 + rho(r, half)) * Hp + h * 32 + c];
+        for (int r = 0; r < 16; ++r) {
+            v[r] = Fac[(x0 + rho(r, half)) * Hp + h * 32 + c];
+            if (rowscale) v[r] *= rowscale[x0 + rho(r, half)];
+        }
         write_factor_tiles<MODE, NH>(Ft, v, xt, h, lane);
-        if constexpr (MODE != MODE_F32) {
+        if (writeback && (MODE != MODE_F32 || rowscale)) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) Fac[(x0 + rho(r, half)) * Hp + h * 32 + c] = v[r];
         }

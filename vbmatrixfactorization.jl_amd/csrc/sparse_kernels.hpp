@@ -19,12 +19,15 @@ namespace vbmf {
 enum : int { S_ZETA = 12, S_ALPHA = 13, S_GAMMA = 14, S_ETA = 15, S_BETA0 = 16, S_DELTA0 = 17, S_ZETA0 = 18 };
 
 // v[h] = sigmaHat * ||B[:,h]||^2 + L * SigmaB[h,h]   (:217; sigmaHat does NOT multiply L*SigmaB: QS2)
+// diag_var (vsq != nullptr): v[h] = sum_l (sigma_l B[l,h])^2 + L * mean(sigma) * SigmaB[h,h]   (:211; S_SIGMA2 holds the mean)
 __global__ void sparse_v_kernel(const double* __restrict__ st, StateLayout lay, int H, double Lg,
-                                double* __restrict__ v) {
+                                double* __restrict__ v, const double* __restrict__ vsq, const int* __restrict__ stop) {
+    if (stop && *stop) return;
     const int h = blockIdx.x * blockDim.x + threadIdx.x;
     if (h >= H) return;
     const long long hh = (long long)h * lay.Hp + h;
-    v[h] = st[lay.scal() + S_SIGMA2] * st[lay.GB() + hh] + Lg * st[lay.SB() + hh];
+    if (vsq) v[h] = vsq[h] + Lg * st[lay.scal() + S_SIGMA2] * st[lay.SB() + hh];
+    else v[h] = st[lay.scal() + S_SIGMA2] * st[lay.GB() + hh] + Lg * st[lay.SB() + hh];
 }
 
 // P: [Hp][ldP] fp32 (x fastest); A32/dS32/CA32: [Mp][Hp] fp32 row-major.  compat: QS1 layout.
@@ -34,8 +37,10 @@ __global__ __launch_bounds__(256) void sparse_update_a_kernel(const float* __res
                                                               const double* __restrict__ st, StateLayout lay,
                                                               float* __restrict__ A32, float* __restrict__ dS32,
                                                               const unsigned char* __restrict__ mask, int hmask_start,
-                                                              long long M, int H, int Hp, int compat) {
-    const double sig = st[lay.scal() + S_SIGMA2];
+                                                              long long M, int H, int Hp, int compat, int unit_sigma,
+                                                              const int* __restrict__ stop) {
+    if (stop && *stop) return;
+    const double sig = unit_sigma ? 1.0 : st[lay.scal() + S_SIGMA2];      // diag_var: sigma is inside P (:230)
     const long long total = M * Hp;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
@@ -60,7 +65,9 @@ __global__ __launch_bounds__(256) void sparse_update_a_kernel(const float* __res
 __global__ __launch_bounds__(256) void sparse_update_ca_kernel(const float* __restrict__ A32,
                                                                const float* __restrict__ dS32,
                                                                float* __restrict__ beta32, float* __restrict__ CA32,
-                                                               double alpha, double beta0, long long M, int H, int Hp) {
+                                                               double alpha, double beta0, long long M, int H, int Hp,
+                                                               const int* __restrict__ stop) {
+    if (stop && *stop) return;
     const long long total = M * Hp;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
@@ -77,9 +84,12 @@ __global__ __launch_bounds__(256) void sparse_update_ca_kernel(const float* __re
 // grid (Hp/32, COLSUM_CHUNKS) partial sums over row chunks, then one block per 32 columns folds the chunks.
 // (One block per 32 columns walking all M rows was latency-bound: 321 us at M = 10 000, H = 256.)
 constexpr int COLSUM_CHUNKS = 32;
+// rs != nullptr: sum of (rs[m] * X[m][h])^2 instead (diag_var: sum_l (sigma_l B[l,h])^2, :211)
 __global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restrict__ X, long long M, int H, int Hp,
-                                                          double* __restrict__ part /* [COLSUM_CHUNKS][Hp] */) {
+                                                          double* __restrict__ part /* [COLSUM_CHUNKS][Hp] */,
+                                                          const float* __restrict__ rs, const int* __restrict__ stop) {
     __shared__ double sh[8][32];
+    if (stop && *stop) return;
     const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
     const int h = blockIdx.x * 32 + c;
     const long long rows = (M + COLSUM_CHUNKS - 1) / COLSUM_CHUNKS;
@@ -87,13 +97,17 @@ __global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restric
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     if (h < H) {
         long long m = m0 + g;
-        for (; m + 24 < m1; m += 32) {
-            a0 += (double)X[m * Hp + h];
-            a1 += (double)X[(m + 8) * Hp + h];
-            a2 += (double)X[(m + 16) * Hp + h];
-            a3 += (double)X[(m + 24) * Hp + h];
+        if (rs) {
+            for (; m < m1; m += 8) { const double t = (double)rs[m] * (double)X[m * Hp + h]; a0 += t * t; }
+        } else {
+            for (; m + 24 < m1; m += 32) {
+                a0 += (double)X[m * Hp + h];
+                a1 += (double)X[(m + 8) * Hp + h];
+                a2 += (double)X[(m + 16) * Hp + h];
+                a3 += (double)X[(m + 24) * Hp + h];
+            }
+            for (; m < m1; m += 8) a0 += (double)X[m * Hp + h];
         }
-        for (; m < m1; m += 8) a0 += (double)X[m * Hp + h];
     }
     sh[g][c] = (a0 + a1) + (a2 + a3);
     __syncthreads();
@@ -103,8 +117,11 @@ __global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restric
         part[(long long)blockIdx.y * Hp + h] = s;
     }
 }
+// vec_out != nullptr: the folded sums go to vec_out[h] only (no SigmaA write)
 __global__ __launch_bounds__(256) void colsum_fold_kernel(const double* __restrict__ part, int H, int Hp,
-                                                          double* __restrict__ st, StateLayout lay) {
+                                                          double* __restrict__ st, StateLayout lay,
+                                                          double* __restrict__ vec_out, const int* __restrict__ stop) {
+    if (stop && *stop) return;
     // block b owns rows [32b, 32b+32) of SigmaA: the diagonal from the chunk partials, zeros elsewhere
     // (SigmaA is diagonal here: write full rows so stale off-diagonals never survive)
     __shared__ double diag[32];
@@ -113,7 +130,9 @@ __global__ __launch_bounds__(256) void colsum_fold_kernel(const double* __restri
         double s = 0.0;
         for (int q = 0; q < COLSUM_CHUNKS; ++q) s += part[(long long)q * Hp + h];
         diag[threadIdx.x] = h < H ? s : 0.0;
+        if (vec_out) vec_out[h] = diag[threadIdx.x];
     }
+    if (vec_out) return;
     __syncthreads();
     for (int t = threadIdx.x; t < 32 * Hp; t += blockDim.x) {
         const int r = t / Hp, j = t - r * Hp, h = blockIdx.x * 32 + r;
@@ -123,9 +142,10 @@ __global__ __launch_bounds__(256) void colsum_fold_kernel(const double* __restri
 
 // SigmaB = inv(diag(CB) + sigmaHat*(GA + SigmaA));  S32 = sigmaHat*SigmaB;  KB = K/sigmaHat (so that
 // B = Q*S32 gives tr(B'Q) = tr(KB * B'B), the identity the basic model uses too).
+// s32_unit (diag_var, :256-261): S32 = SigmaB itself; the per-row sigma_l is applied to the rows of B afterwards
 template <int R, int T>
 __global__ __launch_bounds__(T * T) void sparse_cov_b_kernel(double* __restrict__ st, StateLayout lay, int H,
-                                                             float* __restrict__ S32, int* __restrict__ ints) {
+                                                             float* __restrict__ S32, int* __restrict__ ints, int s32_unit) {
     extern __shared__ __attribute__((aligned(16))) double lds_scb[];
     __shared__ double red[16];
     if (load_stop(ints)) return;
@@ -157,7 +177,7 @@ __global__ __launch_bounds__(T * T) void sparse_cov_b_kernel(double* __restrict_
             const int i = t >> 8, j = t & 255;
             const double v = (i < H && j < H) ? Ki[t] : 0.0;
             st[lay.SB() + (long long)i * Hp + j] = v;
-            S32[(long long)i * Hp + j] = (float)(sig * v);
+            S32[(long long)i * Hp + j] = (float)(s32_unit ? v : sig * v);
         }
     } else {
         double w[R][R];
@@ -185,7 +205,7 @@ __global__ __launch_bounds__(T * T) void sparse_cov_b_kernel(double* __restrict_
                 if (i < Hp && j < Hp) {
                     const double v = (i < H && j < H) ? w[a][b] : 0.0;
                     st[lay.SB() + (long long)i * Hp + j] = v;
-                    S32[(long long)i * Hp + j] = (float)(sig * v);
+                    S32[(long long)i * Hp + j] = (float)(s32_unit ? v : sig * v);
                 }
             }
     }
@@ -275,6 +295,95 @@ __global__ __launch_bounds__(256) void sparse_lb_sums_kernel(const float* __rest
     __syncthreads();
     if (threadIdx.x < 4)
         partials[(long long)blockIdx.x * 4 + threadIdx.x] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+}
+
+// ---- heteroscedastic rows (diag_var = true, src/vbmf_sparse.jl:207-212, 229-230, 256-261, 308-315) ----------
+// ||Y[l,:]||^2 of the STORED matrix, from the pass-2 tiling (x = row l; both lane halves hold the same 32 rows)
+template <int MODE>
+__global__ __launch_bounds__(256) void row_sumsq_kernel(const uint4* __restrict__ Y2, int XT, int KS, long long L,
+                                                        double* __restrict__ yrow) {
+    const int lane = threadIdx.x & 63;
+    const int xt = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (xt >= XT) return;
+    const uint4* p = Y2 + (long long)xt * KS * 64 + lane;
+    double s = 0.0;
+    for (int k = 0; k < KS; ++k) {
+        const uint4 q = p[(long long)k * 64];
+        const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (MODE == MODE_F32) { const double v = (double)__uint_as_float(w[e]); s += v * v; }
+            else {
+                const double lo = (double)__uint_as_float(w[e] << 16), hi = (double)__uint_as_float(w[e] & 0xffff0000u);
+                s += lo * lo + hi * hi;
+            }
+        }
+    }
+    s += __shfl_xor(s, 32);
+    const long long l = (long long)xt * 32 + (lane & 31);
+    if (lane < 32 && l < L) yrow[l] = s;
+}
+
+// G32 = A'A + SigmaA as an fp32 table, scal[S_TRDOT] = tr(G SigmaB)
+__global__ __launch_bounds__(1024) void hetero_g_kernel(double* __restrict__ st, StateLayout lay, int H,
+                                                        float* __restrict__ G32, const int* __restrict__ stop) {
+    __shared__ double red[16];
+    if (stop && *stop) return;
+    const int Hp = lay.Hp;
+    double t = 0.0;
+    for (int i = threadIdx.x; i < Hp * Hp; i += blockDim.x) {
+        const int r = i / Hp, c = i - r * Hp;
+        const double g = (r < H && c < H) ? st[lay.GA() + i] + st[lay.SA() + i] : 0.0;
+        G32[i] = (float)g;
+        if (r < H && c < H) t += g * st[lay.SB() + i];
+    }
+    t = block_sum(t, red);
+    if (threadIdx.x == 0) st[lay.scal() + S_TRDOT] = t;
+}
+
+// zeta_l = zeta0 + ||Y_l||^2/2 - Q[l,:].B[l,:] + (B_l' G B_l + tr(G SigmaB))/2;  sigma_l = etaVec / zeta_l  (:309-314)
+// Q: [Hp][ldQ] (x fastest), B32: [Lp][Hp].  One thread per row; G32 is read as broadcast from L1/L2.
+__global__ __launch_bounds__(256) void hetero_sigma_kernel(const float* __restrict__ Q, long long ldQ,
+                                                           const float* __restrict__ B32, const float* __restrict__ G32,
+                                                           const double* __restrict__ yrow, const double* __restrict__ st,
+                                                           StateLayout lay, double etaVec, long long L, int H, int Hp,
+                                                           double* __restrict__ zetav, double* __restrict__ sigv,
+                                                           float* __restrict__ sig32, double* __restrict__ part,
+                                                           const int* __restrict__ stop) {
+    __shared__ double red[16];
+    if (stop && *stop) return;
+    const long long l = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    double sg = 0.0;
+    if (l < L) {
+        const float* b = B32 + l * Hp;
+        double qb = 0.0, quad = 0.0;
+        for (int h = 0; h < H; ++h) {
+            const float bh = b[h];
+            qb += (double)Q[(long long)h * ldQ + l] * (double)bh;
+            float acc = 0.f;
+            const float* g = G32 + (long long)h * Hp;
+            for (int k = 0; k < H; ++k) acc += g[k] * b[k];
+            quad += (double)bh * (double)acc;
+        }
+        const double z = st[lay.scal() + S_ZETA0] + 0.5 * yrow[l] - qb + 0.5 * (quad + st[lay.scal() + S_TRDOT]);
+        zetav[l] = z;
+        sg = etaVec / z;
+        sigv[l] = sg;
+        sig32[l] = (float)sg;
+    }
+    sg = block_sum(sg, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = sg;
+}
+// scal[S_SIGMA2] = mean(sigmaVecHat)  (what :211 and :257 use)
+__global__ __launch_bounds__(256) void hetero_mean_kernel(const double* __restrict__ part, int n, double L,
+                                                          double* __restrict__ st, StateLayout lay,
+                                                          const int* __restrict__ stop) {
+    __shared__ double red[16];
+    if (stop && *stop) return;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += part[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) st[lay.scal() + S_SIGMA2] = s / L;
 }
 
 // vec(A') (index m*H + h, fp64 host order) <-> [Mp][Hp] fp32

@@ -65,6 +65,12 @@ struct vbmf_ctx {
     // ARD-sparse variant (src/vbmf_sparse.jl, diagonal branch)
     bool sparse = false;
     float *dS32 = nullptr, *CA32 = nullptr, *beta32 = nullptr;   // diagSigmaATVec, CA, beta as [Mp][Hp]
+    // heteroscedastic rows (variant SPARSE_DIAGVAR): sigmaVecHat / zetaVec, ||Y_l||^2, G = A'A + SigmaA, scaled-B tiles
+    bool diagvar = false, Q_valid = false, have_noise = false;
+    double *sigv = nullptr, *zetav = nullptr, *yrow = nullptr, *hpart = nullptr, *vsq = nullptr;
+    float *sig32 = nullptr, *G32 = nullptr;
+    uint4 *FBs_alloc = nullptr, *FBs = nullptr;
+    double etaVec = 0.0;
     double* vtab = nullptr;          // v[h] of src/vbmf_sparse.jl:217
     vbmf_sparse_hyper hyp{};
     double alpha = 0, gamma_ = 0, eta = 0;
@@ -244,7 +250,7 @@ static bool fused_ctrl(const vbmf_ctx* c) { return c->in_run && c->NH <= 4; }
 static int launch_stream(vbmf_ctx* c, int pass, int ctrl_mode = 0) {
     const Dims& d = pass == 0 ? c->d1 : c->d2;
     const uint4* Y = pass == 0 ? c->Y1 : c->Y2;
-    const uint4* F = pass == 0 ? c->FB : c->FA;
+    const uint4* F = pass == 0 ? (c->diagvar ? c->FBs : c->FB) : c->FA;
     float* out = pass == 0 ? c->P : c->Q;
     const long long ld = (long long)d.XT * 32;
     const int XG = d.XT / nxw_of(c->NH);
@@ -333,16 +339,20 @@ static int launch_post_gram(vbmf_ctx* c, int which, const float* In, int nslab) 
     return VBMF_OK;
 }
 
-static int launch_retile(vbmf_ctx* c, int which) {
+// which = 0: A (x tiles of pass 1's factor... i.e. M rows), 1: B (L rows).  Fac -> operand tiles Ft; with writeback the
+// fp32 factor becomes exactly what the tiles encode.  rowscale: per-row factor applied on the way (heteroscedastic rows).
+static int launch_retile_ex(vbmf_ctx* c, int which, float* Fac, uint4* Ft, const float* rowscale, int writeback, bool gated) {
     const Dims& d = which == 0 ? c->d1 : c->d2;
-    float* Fac = which == 0 ? c->A32 : c->B32[c->bcur];
-    uint4* Ft = which == 0 ? c->FA : c->FB;
     const int grid = (d.XT + 3) / 4;
     DISPATCH_MODE(c->mode, DISPATCH_NH(c->NH, {
-        hipLaunchKernelGGL((retile_kernel<MODEc, NHc>), dim3(grid), dim3(256), 0, c->stream, Fac, Ft, d.XT);
+        hipLaunchKernelGGL((retile_kernel<MODEc, NHc>), dim3(grid), dim3(256), 0, c->stream, Fac, Ft, d.XT, rowscale, writeback,
+                           gated ? c->ints + I_STOP : (const int*)nullptr);
     }));
     HIPCHK(c, hipGetLastError());
     return VBMF_OK;
+}
+static int launch_retile(vbmf_ctx* c, int which, bool gated = false) {
+    return launch_retile_ex(c, which, which == 0 ? c->A32 : c->B32[c->bcur], which == 0 ? c->FA : c->FB, nullptr, 1, gated);
 }
 
 // Gram of A (which=0) or of B with optional delta-Gram against prev (which=1) into the state block.
@@ -601,7 +611,8 @@ int vbmf_destroy(vbmf_ctx* c) {
     prof_harvest(c);
     if (c->comm) ncclCommDestroy(c->comm);
     void* bufs[] = {c->Y1, c->Y2, c->FA_alloc, c->FB_alloc, c->P, c->Q, c->Pred, c->A32, c->B32[0], c->B32[1], c->SA32,
-                    c->SB32, c->gslab, c->st, c->gtmp, c->ypart, c->ints, c->mask, c->dS32, c->CA32, c->beta32, c->vtab};
+                    c->SB32, c->gslab, c->st, c->gtmp, c->ypart, c->ints, c->mask, c->dS32, c->CA32, c->beta32, c->vtab,
+                    c->sigv, c->zetav, c->yrow, c->hpart, c->vsq, c->sig32, c->G32, c->FBs_alloc};
     for (void* b : bufs) if (b) hipFree(b);
     if (c->ints_host) hipHostFree(c->ints_host);
     if (c->scal_host) hipHostFree(c->scal_host);
@@ -623,8 +634,11 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
     }
     if (L <= 0 || M <= 0 || H <= 0) { c->err = "L, M, H must be positive"; return bail(VBMF_ERR_INVALID); }
     if (H > 256) { c->err = "H > 256 is not supported"; return bail(VBMF_ERR_UNSUPPORTED); }
-    if (c->o.variant != VBMF_VARIANT_BASIC && c->o.variant != VBMF_VARIANT_SPARSE_DIAG) { c->err = "unknown variant"; return bail(VBMF_ERR_INVALID); }
-    c->sparse = (c->o.variant == VBMF_VARIANT_SPARSE_DIAG);
+    if (c->o.variant != VBMF_VARIANT_BASIC && c->o.variant != VBMF_VARIANT_SPARSE_DIAG && c->o.variant != VBMF_VARIANT_SPARSE_DIAGVAR) {
+        c->err = "unknown variant"; return bail(VBMF_ERR_INVALID);
+    }
+    c->sparse = (c->o.variant != VBMF_VARIANT_BASIC);
+    c->diagvar = (c->o.variant == VBMF_VARIANT_SPARSE_DIAGVAR);
     if (c->sparse && opts && opts->nranks > 1) { c->err = "the sparse variant is single-GPU in this round"; return bail(VBMF_ERR_UNSUPPORTED); }
     if (c->o.nranks < 1 || c->o.rank < 0 || c->o.rank >= c->o.nranks) { c->err = "bad nranks/rank"; return bail(VBMF_ERR_INVALID); }
     int ndev = 0;
@@ -707,6 +721,17 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
         ALLOC(c->beta32, (size_t)c->Mp * c->Hp * 4);
         ALLOC(c->vtab, (size_t)c->Hp * 8);
     }
+    if (c->diagvar) {
+        ALLOC(c->sigv, (size_t)c->Lp * 8);
+        ALLOC(c->zetav, (size_t)c->Lp * 8);
+        ALLOC(c->yrow, (size_t)c->Lp * 8);
+        ALLOC(c->hpart, (size_t)cdiv(c->Lp, 256) * 8 + 64);
+        ALLOC(c->vsq, (size_t)c->Hp * 8);
+        ALLOC(c->sig32, (size_t)c->Lp * 4);
+        ALLOC(c->G32, (size_t)c->Hp * c->Hp * 4);
+        ALLOC(c->FBs_alloc, (c->nFB + flead) * 16);
+        c->FBs = c->FBs_alloc + flead;
+    }
 #undef ALLOC
     if (hipHostMalloc((void**)&c->ints_host, 16 * sizeof(int)) != hipSuccess ||
         hipHostMalloc((void**)&c->scal_host, 32 * sizeof(double)) != hipSuccess) {
@@ -763,7 +788,17 @@ static int finish_Y(vbmf_ctx* c) {
     c->trYY_reduced = !sharded(c) && c->o.nranks == 1;
     c->haveY = true;
     c->P_valid = false;
+    c->Q_valid = false;
     c->kb_identity = false;
+    if (c->diagvar) {                                  // ||Y_l||^2 of every row (:310), from the stored values
+        DISPATCH_MODE(c->mode, {
+            constexpr int TM = (MODEc == MODE_F32) ? MODE_F32 : MODE_BF16;
+            hipLaunchKernelGGL((row_sumsq_kernel<TM>), dim3((c->d2.XT + 3) / 4), dim3(256), 0, c->stream, c->Y2, c->d2.XT, c->d2.KS,
+                               (long long)c->L, c->yrow);
+        });
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     return VBMF_OK;
 }
 
@@ -1346,7 +1381,7 @@ static double digamma_host(double x) {
 template <int R, int T>
 static void launch_scov_t(vbmf_ctx* c) {
     const size_t lds = (R == 8 && T == 32) ? (size_t)(2 * 16 * GEMM_LD + 512 + 256) * sizeof(double) : (size_t)(5 * T * R) * sizeof(double);
-    hipLaunchKernelGGL((sparse_cov_b_kernel<R, T>), dim3(1), dim3(T * T), lds, c->stream, c->st, c->lay, (int)c->H, c->SB32, c->ints);
+    hipLaunchKernelGGL((sparse_cov_b_kernel<R, T>), dim3(1), dim3(T * T), lds, c->stream, c->st, c->lay, (int)c->H, c->SB32, c->ints, c->diagvar ? 1 : 0);
 }
 static int launch_sparse_cov_b(vbmf_ctx* c) {
     const int H = (int)c->H;
@@ -1361,31 +1396,48 @@ static int launch_sparse_cov_b(vbmf_ctx* c) {
 
 static int sparse_colsum(vbmf_ctx* c) {
     double* part = c->st + c->lay.W1();      // scratch: COLSUM_CHUNKS * Hp <= Hp * Hp doubles (Hp >= 32)
-    hipLaunchKernelGGL(colsum_part_kernel, dim3(c->Hp / 32, COLSUM_CHUNKS), dim3(256), 0, c->stream, c->dS32, (long long)c->M, (int)c->H, c->Hp, part);
-    hipLaunchKernelGGL(colsum_fold_kernel, dim3(c->Hp / 32), dim3(256), 0, c->stream, part, (int)c->H, c->Hp, c->st, c->lay);
+    const int* stop = c->ints + I_STOP;
+    hipLaunchKernelGGL(colsum_part_kernel, dim3(c->Hp / 32, COLSUM_CHUNKS), dim3(256), 0, c->stream, c->dS32, (long long)c->M, (int)c->H, c->Hp, part,
+                       (const float*)nullptr, stop);
+    hipLaunchKernelGGL(colsum_fold_kernel, dim3(c->Hp / 32), dim3(256), 0, c->stream, part, (int)c->H, c->Hp, c->st, c->lay, (double*)nullptr, stop);
     HIPCHK(c, hipGetLastError());
     return VBMF_OK;
 }
 
 static int do_sparse_update_A(vbmf_ctx* c, bool reuse_P = false) {
     TRY(ensure_gram_B(c));
-    hipLaunchKernelGGL(sparse_v_kernel, dim3((c->Hp + 63) / 64), dim3(64), 0, c->stream, c->st, c->lay, (int)c->H, (double)c->Lg, c->vtab);
+    const int* stop = c->ints + I_STOP;
+    if (c->diagvar) {
+        // :211, :230 -- B enters as diag(sigmaVecHat) * B: tiles of the row-scaled factor for the pass, and
+        // sum_l (sigma_l B[l,h])^2 for the precision of vec(A')
+        if (!c->have_noise) FAIL(c, VBMF_ERR_INVALID, "no row noise state: call vbmf_sparse_set_noise_rows first");
+        TRY(launch_retile_ex(c, 1, c->B32[c->bcur], c->FBs, c->sig32, 0, true));
+        double* part = c->st + c->lay.W1();
+        hipLaunchKernelGGL(colsum_part_kernel, dim3(c->Hp / 32, COLSUM_CHUNKS), dim3(256), 0, c->stream, c->B32[c->bcur], (long long)c->L,
+                           (int)c->H, c->Hp, part, (const float*)c->sig32, stop);
+        hipLaunchKernelGGL(colsum_fold_kernel, dim3(c->Hp / 32), dim3(256), 0, c->stream, part, (int)c->H, c->Hp, c->st, c->lay, c->vsq, stop);
+        reuse_P = false;                            // sigma changes every iteration, so does Y' diag(sigma) B
+    }
+    hipLaunchKernelGGL(sparse_v_kernel, dim3((c->Hp + 63) / 64), dim3(64), 0, c->stream, c->st, c->lay, (int)c->H, (double)c->Lg, c->vtab,
+                       c->diagvar ? (const double*)c->vsq : (const double*)nullptr, stop);
     if (!(reuse_P && c->P_valid)) {
         TRY(launch_stream(c, 0));
         const long long n = (long long)c->Hp * c->d1.XT * 32;
-        hipLaunchKernelGGL(slab_sum_kernel, dim3(grid_for(n / 4, 256, 2048)), dim3(256), 0, c->stream, c->P, c->d1.nsplit, n, c->Pred, n, c->ints + I_STOP);
+        hipLaunchKernelGGL(slab_sum_kernel, dim3(grid_for(n / 4, 256, 2048)), dim3(256), 0, c->stream, c->P, c->d1.nsplit, n, c->Pred, n, stop);
     }
     const int compat = (c->o.reference_compat & VBMF_COMPAT_SPARSE_REPEAT) ? 1 : 0;
     if (compat && c->M < 2) FAIL(c, VBMF_ERR_INVALID, "repeat(v, inner=M-1) needs M >= 2");
     hipLaunchKernelGGL(sparse_update_a_kernel, dim3(grid_for((int64_t)c->M * c->Hp)), dim3(256), 0, c->stream, c->Pred,
                        (long long)c->d1.XT * 32, c->CA32, c->vtab, c->st, c->lay, c->A32, c->dS32,
-                       c->has_mask ? c->mask : nullptr, (int)(c->H - c->H1), (long long)c->M, (int)c->H, c->Hp, compat);
+                       c->has_mask ? c->mask : nullptr, (int)(c->H - c->H1), (long long)c->M, (int)c->H, c->Hp, compat,
+                       c->diagvar ? 1 : 0, stop);
     HIPCHK(c, hipGetLastError());
-    TRY(launch_retile(c, 0));                       // operand tiles; A32 := the value the tiles encode
-    TRY(launch_gram(c, 0, c->A32, nullptr, false));
+    TRY(launch_retile(c, 0, true));                 // operand tiles; A32 := the value the tiles encode
+    TRY(launch_gram(c, 0, c->A32, nullptr, true));
     TRY(sparse_colsum(c));                          // SigmaA = diag(sum_m diagSigma)
     c->gA_valid = true;
-    c->P_valid = true;
+    c->P_valid = !c->diagvar;
+    c->Q_valid = false;
     c->kb_identity = false;
     return VBMF_OK;
 }
@@ -1395,22 +1447,43 @@ static int do_sparse_update_B(vbmf_ctx* c) {
     TRY(launch_sparse_cov_b(c));
     TRY(launch_stream(c, 1));
     TRY(fold_Q_slabs(c));
-    if (fused_gram(c)) {
+    if (fused_gram(c) && !c->diagvar) {
         TRY(launch_post_gram(c, 1, c->Q, 1));
     } else {
         TRY(launch_post(c, 1, c->Q, 1));
-        TRY(launch_gram(c, 1, c->B32[c->bcur ^ 1], c->B32[c->bcur], false));
+        // :261 -- B = diag(sigmaVecHat) * Y A SigmaB: the post kernel applied SigmaB, the rows are scaled here
+        if (c->diagvar) TRY(launch_retile_ex(c, 1, c->B32[c->bcur ^ 1], c->FB, c->sig32, 1, true));
+        TRY(launch_gram(c, 1, c->B32[c->bcur ^ 1], c->B32[c->bcur], true));
     }
     c->bcur ^= 1;
     c->gB_valid = true;
     c->P_valid = false;
-    c->kb_identity = true;
+    c->Q_valid = true;
+    c->kb_identity = !c->diagvar;
+    return VBMF_OK;
+}
+
+// updateSigma!, diag_var = true (:308-315): every row's Gamma posterior; S_SIGMA2 := mean(sigmaVecHat)
+static int do_hetero_sigma(vbmf_ctx* c) {
+    TRY(ensure_gram_A(c));
+    if (!c->Q_valid) {                              // Y*A for the current A (not left over from updateB!)
+        TRY(launch_stream(c, 1));
+        TRY(fold_Q_slabs(c));
+        c->Q_valid = true;
+    }
+    const int* stop = c->ints + I_STOP;
+    hipLaunchKernelGGL(hetero_g_kernel, dim3(1), dim3(1024), 0, c->stream, c->st, c->lay, (int)c->H, c->G32, stop);
+    const int nb = (int)cdiv(c->L, 256);
+    hipLaunchKernelGGL(hetero_sigma_kernel, dim3(nb), dim3(256), 0, c->stream, c->Q, (long long)c->d2.XT * 32, c->B32[c->bcur], c->G32,
+                       c->yrow, c->st, c->lay, c->etaVec, (long long)c->L, (int)c->H, c->Hp, c->zetav, c->sigv, c->sig32, c->hpart, stop);
+    hipLaunchKernelGGL(hetero_mean_kernel, dim3(1), dim3(256), 0, c->stream, c->hpart, nb, (double)c->L, c->st, c->lay, stop);
+    HIPCHK(c, hipGetLastError());
     return VBMF_OK;
 }
 
 static int sparse_update_CA(vbmf_ctx* c) {
     hipLaunchKernelGGL(sparse_update_ca_kernel, dim3(grid_for((int64_t)c->M * c->Hp)), dim3(256), 0, c->stream, c->A32, c->dS32,
-                       c->beta32, c->CA32, c->alpha, c->hyp.beta0, (long long)c->M, (int)c->H, c->Hp);
+                       c->beta32, c->CA32, c->alpha, c->hyp.beta0, (long long)c->M, (int)c->H, c->Hp, c->ints + I_STOP);
     HIPCHK(c, hipGetLastError());
     return VBMF_OK;
 }
@@ -1499,6 +1572,8 @@ int vbmf_sparse_set_state(vbmf_ctx* c, const double* ATVecHat, const double* dia
     HIPCHK(c, hipMemsetAsync(c->ints, 0, 16 * sizeof(int), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->gA_valid = c->gB_valid = c->P_valid = c->kb_identity = false;
+    c->Q_valid = false;
+    c->have_noise = false;
     c->haveState = true;
     return VBMF_OK;
 }
@@ -1541,7 +1616,11 @@ int vbmf_sparse_step(vbmf_ctx* c, int which) {
     if (which & VBMF_SSTEP_CA) TRY(sparse_update_CA(c));
     int flags = 0;
     if (which & VBMF_SSTEP_CB) { TRY(ensure_gram_B(c)); flags |= 2; }
-    if (which & VBMF_SSTEP_SIGMA) {
+    if ((which & VBMF_SSTEP_SIGMA) && c->diagvar) {
+        if (flags) TRY(launch_sparse_ctrl_end(c, flags, 0.0, nullptr));
+        flags = 0;
+        TRY(do_hetero_sigma(c));
+    } else if (which & VBMF_SSTEP_SIGMA) {
         TRY(ensure_gram_A(c));
         TRY(ensure_gram_B(c));
         int f = 0;
@@ -1563,6 +1642,10 @@ int vbmf_sparse_run_fixed_basis(vbmf_ctx* c, int64_t niter) {
         TRY(do_sparse_update_A(c, true));
         TRY(sparse_update_CA(c));
         TRY(ensure_gram_A(c));
+        if (c->diagvar) {                               // sigma_l changes Y' diag(sigma) B every iteration: both passes
+            TRY(do_hetero_sigma(c));
+            continue;
+        }
         int f = 0;
         TRY(prepare_trYBA(c, &f));
         TRY(launch_sparse_ctrl_end(c, 4 | f, 0.0, nullptr));
@@ -1592,7 +1675,8 @@ int vbmf_sparse_run(vbmf_ctx* c, int64_t niter, double eps, int est_cb, int64_t*
     if (rc == VBMF_OK) rc = launch_eig(c, 0, 1);
     if (rc == VBMF_OK)
         hipLaunchKernelGGL(copy_scalar_kernel, dim3(1), dim3(1), 0, c->stream, c->st, c->lay, (int)S_LAMB_PREV, (int)S_LAMB_NEW);
-    const int flags = (est_cb ? 2 : 0) | 4 | 8 | 16;
+    // diag_var: the rows' noise update (:308-315) replaces the scalar one and runs before the stop test of the sweep
+    const int flags = (est_cb ? 2 : 0) | (c->diagvar ? 0 : 4 | 16) | 8;
     const int bstart = c->bcur;
     int64_t it = 0;
     bool stopped = false;
@@ -1600,6 +1684,7 @@ int vbmf_sparse_run(vbmf_ctx* c, int64_t niter, double eps, int est_cb, int64_t*
         rc = do_sparse_update_A(c);
         if (rc == VBMF_OK) rc = do_sparse_update_B(c);
         if (rc == VBMF_OK) rc = sparse_update_CA(c);
+        if (rc == VBMF_OK && c->diagvar) rc = do_hetero_sigma(c);
         if (rc == VBMF_OK) rc = launch_eig(c, 1, 1);
         if (rc == VBMF_OK) rc = launch_sparse_ctrl_end(c, flags, eps, trace_dev);
         ++it;
@@ -1629,13 +1714,44 @@ int vbmf_sparse_run(vbmf_ctx* c, int64_t niter, double eps, int est_cb, int64_t*
     if (trace_dev) hipFree(trace_dev);
     c->gA_valid = c->gB_valid = true;
     c->P_valid = false;
-    c->kb_identity = true;
+    c->Q_valid = false;
+    c->kb_identity = !c->diagvar;
     return rc;
+}
+
+// sigmaVecHat, zetaVec (length L each) and the common shape etaVec = eta0 + M/2 (src/vbmf_sparse.jl:145-147) of the
+// heteroscedastic model (opts.variant = VBMF_VARIANT_SPARSE_DIAGVAR).  Call after vbmf_sparse_set_state.
+int vbmf_sparse_set_noise_rows(vbmf_ctx* c, const double* sigmaVecHat, const double* zetaVec, double etaVec) {
+    if (!c || !sigmaVecHat || !zetaVec) return VBMF_ERR_INVALID;
+    if (!c->diagvar) FAIL(c, VBMF_ERR_INVALID, "not a heteroscedastic context (opts.variant)");
+    HIPCHK(c, hipSetDevice(c->o.device));
+    std::vector<float> s32((size_t)c->Lp, 0.f);
+    double mean = 0.0;
+    for (int64_t l = 0; l < c->L; ++l) { s32[(size_t)l] = (float)sigmaVecHat[l]; mean += sigmaVecHat[l]; }
+    mean /= (double)c->L;
+    HIPCHK(c, hipMemcpy(c->sigv, sigmaVecHat, (size_t)c->L * 8, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->zetav, zetaVec, (size_t)c->L * 8, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->sig32, s32.data(), (size_t)c->Lp * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->st + c->lay.scal() + S_SIGMA2, &mean, 8, hipMemcpyHostToDevice));
+    c->etaVec = etaVec;
+    c->have_noise = true;
+    return VBMF_OK;
+}
+
+int vbmf_sparse_get_noise_rows(vbmf_ctx* c, double* sigmaVecHat, double* zetaVec) {
+    if (!c) return VBMF_ERR_INVALID;
+    if (!c->diagvar || !c->have_noise) FAIL(c, VBMF_ERR_INVALID, "no row noise state");
+    HIPCHK(c, hipSetDevice(c->o.device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (sigmaVecHat) HIPCHK(c, hipMemcpy(sigmaVecHat, c->sigv, (size_t)c->L * 8, hipMemcpyDeviceToHost));
+    if (zetaVec) HIPCHK(c, hipMemcpy(zetaVec, c->zetav, (size_t)c->L * 8, hipMemcpyDeviceToHost));
+    return VBMF_OK;
 }
 
 int vbmf_sparse_lower_bound(vbmf_ctx* c, int clamp, double* lb) {
     if (!c || !lb) return VBMF_ERR_INVALID;
     if (!c->sparse) FAIL(c, VBMF_ERR_INVALID, "not a sparse context");
+    if (c->diagvar) FAIL(c, VBMF_ERR_UNSUPPORTED, "lowerBound is defined for the homoscedastic model only (src/vbmf_sparse.jl:435)");
     HIPCHK(c, hipSetDevice(c->o.device));
     TRY(ensure_ready(c));
     TRY(ensure_gram_A(c));
