@@ -52,14 +52,20 @@ def _spawn(world, transport, outdir, case):
 def _check(pkg, world, transport, tmp_path, case="h12"):
     L, M, H = W.CASES[case]
     Y, A0, B0 = W.problem(L, M, H, W.SEED)
-    with pkg.capi.Context(L, M, H, y_dtype=pkg.VBMF_Y_BF16) as c:
-        ref = W.run(pkg, c, Y, A0, B0, H, W.NITERS[case])
+    with pkg.capi.Context(L, M, H, y_dtype=pkg.VBMF_Y_BF16, variant=W.variant_of(pkg, case)) as c:
+        if case in ("sparse", "hetero"):
+            ref = W.run_sparse(pkg, c, Y, A0, B0, H, W.NITERS[case], case == "hetero", L, 0)
+        else:
+            ref = W.run(pkg, c, Y, A0, B0, H, W.NITERS[case])
     ranks = _spawn(world, transport, tmp_path, case)
     # replicated quantities are bit-identical across the ranks (they see the same reduced sums)
     for k in ("AHat", "SigmaA", "SigmaB", "CA_diag", "CB_diag", "sigma2", "d", "trace", "trYY", "it"):
         for r in ranks[1:]:
             assert np.array_equal(ranks[0][k], r[k]), k
     B = np.concatenate([r["BHat"] for r in ranks], axis=0)
+    if case == "hetero":                                     # the rows' precisions live with the rows
+        sv = np.concatenate([r["sigmaVecHat"] for r in ranks])
+        assert relF(sv, ref["sigmaVecHat"]) < 5e-3, relF(sv, ref["sigmaVecHat"])
     assert [int(r["row0"]) for r in ranks] == [pkg.dist.row_shard(L, world, i)[0] for i in range(world)]
     assert B.shape == (L, H) and int(ranks[0]["it"]) == ref["it"] == W.NITERS[case]
     errs = dict(A=relF(ranks[0]["AHat"], ref["AHat"]), B=relF(B, ref["BHat"]),
@@ -68,14 +74,17 @@ def _check(pkg, world, transport, tmp_path, case="h12"):
                 s2=abs(float(ranks[0]["sigma2"]) - ref["sigma2"]) / ref["sigma2"],
                 trYY=abs(float(ranks[0]["trYY"]) - ref["trYY"]) / ref["trYY"],
                 d=abs(float(ranks[0]["d"]) - ref["d"]) / ref["d"],
-                elbo=abs(float(ranks[0]["elbo"]) - ref["elbo"]) / abs(ref["elbo"]))
+                elbo=abs(float(ranks[0]["elbo"]) - ref["elbo"]) / max(abs(ref["elbo"]), 1e-300))
     report(f"{world} ranks ({transport} transport) vs 1 rank, {L}x{M} H={H}, {W.NITERS[case]} sweeps: "
            + " ".join(f"{k}={v:.2e}" for k, v in errs.items()))
     # same arithmetic, different summation order of the row partials (fp32 partial sums of Y'B, fp64 Grams).
     # sigma2 is the reference's cancelling difference ||Y||^2 - 2tr + tr (x ~400 here), and SigmaA/SigmaB scale
     # with it, so those see the fp32 reordering noise amplified; d is a difference of fp32-stored factors.
-    assert max(errs[k] for k in ("A", "B", "ca", "cb")) < 2e-5, errs
-    assert max(errs[k] for k in ("SA", "SB", "s2")) < 5e-4, errs
+    # The sparse model's element-wise ARD (CA = alpha/beta with beta ~ A^2 + diagSigma, entries pruned over many orders
+    # of magnitude) amplifies that reordering noise further: scalars (sigma, d, the bound) still agree to 1e-6.
+    k = 50.0 if case in ("sparse", "hetero") else 1.0
+    assert max(errs[k_] for k_ in ("A", "B", "ca", "cb")) < 2e-5 * k, errs
+    assert max(errs[k_] for k_ in ("SA", "SB", "s2")) < 5e-4 * (2.0 if k > 1 else 1.0), errs
     assert errs["trYY"] < 1e-12 and errs["elbo"] < 1e-4, errs
     assert abs(float(ranks[0]["d"]) - ref["d"]) < 2e-2 * ref["d"] + 2e-6, errs
 
@@ -90,6 +99,13 @@ def test_three_ranks_one_gpu_host_transport(pkg, tmp_path):
 
 @pytest.mark.parametrize("case", ["h128", "h200"])
 def test_two_ranks_large_rank_paths(pkg, tmp_path, case):
+    _check(pkg, 2, "host", tmp_path, case)
+
+
+@pytest.mark.parametrize("case", ["sparse", "hetero"])
+def test_two_ranks_sparse_variant(pkg, tmp_path, case):
+    """vbmf_sparse! row-sharded (homoscedastic, and one noise precision per row): Y'B, the Grams, ||Y||^2, and in the
+    heteroscedastic model sum_l (sigma_l B_lh)^2 and mean(sigma) are summed over the ranks."""
     _check(pkg, 2, "host", tmp_path, case)
 
 

@@ -24,9 +24,36 @@ def problem(L, M, H, seed):
 
 # name -> (L, M, H): L deliberately not a multiple of the rank count.  "h128" runs the H = 128 kernels of the
 # 8-GPU BASELINE configuration (16 accumulator tiles per wave, un-fused post/Gram), "h200" the H > 128 control path.
-CASES = {"h12": (1531, 700, 12), "h128": (1203, 520, 128), "h200": (901, 420, 200)}
+# "sparse" / "hetero": the ARD-sparse variant (homoscedastic / one noise precision per row) row-sharded.
+CASES = {"h12": (1531, 700, 12), "h128": (1203, 520, 128), "h200": (901, 420, 200), "sparse": (1101, 480, 6),
+         "hetero": (1101, 480, 6)}
 EPS, SEED = 0.0, 4242
-NITERS = {"h12": 12, "h128": 5, "h200": 5}
+NITERS = {"h12": 12, "h128": 5, "h200": 5, "sparse": 8, "hetero": 8}
+HYPER = dict(alpha0=1e-10, beta0=1e-10, gamma0=1e-10, delta0=1e-10, eta0=1e-10, zeta0=1e-10)
+
+
+def variant_of(pkg, case):
+    return {"sparse": pkg.capi.VBMF_VARIANT_SPARSE_DIAG, "hetero": pkg.capi.VBMF_VARIANT_SPARSE_DIAGVAR}.get(case, pkg.capi.VBMF_VARIANT_BASIC)
+
+
+def run_sparse(pkg, ctx, Y, A0, B0, H, niter, hetero, L_global, row0):
+    """vbmf_sparse_init's initial state (src/vbmf_sparse.jl:101-153, ca = cb = sigma = 1) on this rank's rows."""
+    M = A0.shape[0]
+    n = Y.shape[0]
+    ctx.set_Y(Y)
+    ctx.sparse_set_state(A0.reshape(M * H), np.ones(M * H), np.ones(M * H), 1e-10 * np.ones(M * H), B0, np.zeros((H, H)),
+                         np.ones(H), 1e-10 * np.ones(H), 1.0, 1e-10, HYPER)
+    if hetero:
+        ctx.sparse_set_noise_rows(np.ones(n), 1e-10 * np.ones(n), 1e-10 + M / 2)
+    it, d, _ = ctx.sparse_run(niter, eps=EPS, est_cb=True)
+    s = ctx.sparse_get_state()
+    out = dict(it=it, d=d, trYY=ctx.trYY(), AHat=s["ATVecHat"].reshape(M, H), BHat=s["BHat"], SigmaA=np.diag(s["SigmaA_diag"]),
+               SigmaB=s["SigmaB"], CA_diag=s["CA"], CB_diag=s["CB"], sigma2=s["sigmaHat"], trace=np.zeros(1),
+               elbo=0.0 if hetero else ctx.sparse_lower_bound())
+    if hetero:
+        out["sigmaVecHat"], out["zetaVec"] = ctx.sparse_get_noise_rows()
+    return out
+
 
 
 def run(pkg, ctx, Y, A0, B0, H, niter):
@@ -52,14 +79,17 @@ def main():
     r0, n = pkg.dist.row_shard(L, world, rank)
     dev = rank if transport == "rccl" else 0
     with pkg.capi.Context(n, M, H, y_dtype=pkg.VBMF_Y_BF16, device=dev, nranks=world, rank=rank, L_global=L,
-                          row_offset=r0) as ctx:
+                          row_offset=r0, variant=variant_of(pkg, case)) as ctx:
         if transport == "rccl":
             uid = [pkg.capi.Context.unique_id() if rank == 0 else None]
             dist.broadcast_object_list(uid, src=0)
             ctx.comm_init(uid[0])
         else:
             ctx.comm_set_transport(pkg.dist.host_staged_transport(lambda a: dist.all_reduce(torch.from_numpy(a))))
-        res = run(pkg, ctx, Y[r0:r0 + n], A0, B0[r0:r0 + n], H, NITERS[case])
+        if case in ("sparse", "hetero"):
+            res = run_sparse(pkg, ctx, Y[r0:r0 + n], A0, B0[r0:r0 + n], H, NITERS[case], case == "hetero", L, r0)
+        else:
+            res = run(pkg, ctx, Y[r0:r0 + n], A0, B0[r0:r0 + n], H, NITERS[case])
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), row0=r0, nrows=n, **res)
     dist.barrier()
     dist.destroy_process_group()

@@ -376,14 +376,13 @@ __global__ __launch_bounds__(256) void hetero_sigma_kernel(const float* __restri
 }
 // scal[S_SIGMA2] = mean(sigmaVecHat)  (what :211 and :257 use)
 __global__ __launch_bounds__(256) void hetero_mean_kernel(const double* __restrict__ part, int n, double L,
-                                                          double* __restrict__ st, StateLayout lay,
-                                                          const int* __restrict__ stop) {
+                                                          double* __restrict__ out, const int* __restrict__ stop) {
     __shared__ double red[16];
     if (stop && *stop) return;
     double s = 0.0;
     for (int i = threadIdx.x; i < n; i += blockDim.x) s += part[i];
     s = block_sum(s, red);
-    if (threadIdx.x == 0) st[lay.scal() + S_SIGMA2] = s / L;
+    if (threadIdx.x == 0) *out = s / L;
 }
 
 // vec(A') (index m*H + h, fp64 host order) <-> [Mp][Hp] fp32

@@ -66,7 +66,7 @@ struct vbmf_ctx {
     bool sparse = false;
     float *dS32 = nullptr, *CA32 = nullptr, *beta32 = nullptr;   // diagSigmaATVec, CA, beta as [Mp][Hp]
     // heteroscedastic rows (variant SPARSE_DIAGVAR): sigmaVecHat / zetaVec, ||Y_l||^2, G = A'A + SigmaA, scaled-B tiles
-    bool diagvar = false, Q_valid = false, have_noise = false;
+    bool diagvar = false, Q_valid = false, have_noise = false, noise_mean_reduced = false;
     double *sigv = nullptr, *zetav = nullptr, *yrow = nullptr, *hpart = nullptr, *vsq = nullptr;
     float *sig32 = nullptr, *G32 = nullptr;
     uint4 *FBs_alloc = nullptr, *FBs = nullptr;
@@ -449,6 +449,10 @@ static int ensure_ready(vbmf_ctx* c) {
         TRY(allreduce_sum(c, dst, 1, true));
         c->trYY_reduced = true;
     }
+    if (c->diagvar && c->have_noise && !c->noise_mean_reduced) {
+        if (sharded(c)) TRY(allreduce_sum(c, c->st + c->lay.scal() + S_SIGMA2, 1, true));   // shares of mean(sigmaVecHat)
+        c->noise_mean_reduced = true;
+    }
     return VBMF_OK;
 }
 
@@ -639,7 +643,6 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
     }
     c->sparse = (c->o.variant != VBMF_VARIANT_BASIC);
     c->diagvar = (c->o.variant == VBMF_VARIANT_SPARSE_DIAGVAR);
-    if (c->sparse && opts && opts->nranks > 1) { c->err = "the sparse variant is single-GPU in this round"; return bail(VBMF_ERR_UNSUPPORTED); }
     if (c->o.nranks < 1 || c->o.rank < 0 || c->o.rank >= c->o.nranks) { c->err = "bad nranks/rank"; return bail(VBMF_ERR_INVALID); }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -1416,6 +1419,7 @@ static int do_sparse_update_A(vbmf_ctx* c, bool reuse_P = false) {
         hipLaunchKernelGGL(colsum_part_kernel, dim3(c->Hp / 32, COLSUM_CHUNKS), dim3(256), 0, c->stream, c->B32[c->bcur], (long long)c->L,
                            (int)c->H, c->Hp, part, (const float*)c->sig32, stop);
         hipLaunchKernelGGL(colsum_fold_kernel, dim3(c->Hp / 32), dim3(256), 0, c->stream, part, (int)c->H, c->Hp, c->st, c->lay, c->vsq, stop);
+        if (sharded(c)) TRY(allreduce_sum(c, c->vsq, (size_t)c->Hp, true));    // scratch, rebuilt before every use
         reuse_P = false;                            // sigma changes every iteration, so does Y' diag(sigma) B
     }
     hipLaunchKernelGGL(sparse_v_kernel, dim3((c->Hp + 63) / 64), dim3(64), 0, c->stream, c->st, c->lay, (int)c->H, (double)c->Lg, c->vtab,
@@ -1424,6 +1428,7 @@ static int do_sparse_update_A(vbmf_ctx* c, bool reuse_P = false) {
         TRY(launch_stream(c, 0));
         const long long n = (long long)c->Hp * c->d1.XT * 32;
         hipLaunchKernelGGL(slab_sum_kernel, dim3(grid_for(n / 4, 256, 2048)), dim3(256), 0, c->stream, c->P, c->d1.nsplit, n, c->Pred, n, stop);
+        if (sharded(c)) TRY(allreduce_sum(c, c->Pred, (size_t)n, false));      // Y'B summed over the row shards
     }
     const int compat = (c->o.reference_compat & VBMF_COMPAT_SPARSE_REPEAT) ? 1 : 0;
     if (compat && c->M < 2) FAIL(c, VBMF_ERR_INVALID, "repeat(v, inner=M-1) needs M >= 2");
@@ -1476,7 +1481,14 @@ static int do_hetero_sigma(vbmf_ctx* c) {
     const int nb = (int)cdiv(c->L, 256);
     hipLaunchKernelGGL(hetero_sigma_kernel, dim3(nb), dim3(256), 0, c->stream, c->Q, (long long)c->d2.XT * 32, c->B32[c->bcur], c->G32,
                        c->yrow, c->st, c->lay, c->etaVec, (long long)c->L, (int)c->H, c->Hp, c->zetav, c->sigv, c->sig32, c->hpart, stop);
-    hipLaunchKernelGGL(hetero_mean_kernel, dim3(1), dim3(256), 0, c->stream, c->hpart, nb, (double)c->L, c->st, c->lay, stop);
+    if (sharded(c)) {
+        // this rank's share of the mean goes through the staging buffer: after `stop` the state must not be re-summed
+        hipLaunchKernelGGL(hetero_mean_kernel, dim3(1), dim3(256), 0, c->stream, c->hpart, nb, (double)c->Lg, c->gtmp, stop);
+        TRY(allreduce_sum(c, c->gtmp, 1, true));
+        hipLaunchKernelGGL(gated_copy_kernel, dim3(1), dim3(64), 0, c->stream, c->gtmp, c->st + c->lay.scal() + S_SIGMA2, 1, stop);
+    } else {
+        hipLaunchKernelGGL(hetero_mean_kernel, dim3(1), dim3(256), 0, c->stream, c->hpart, nb, (double)c->L, c->st + c->lay.scal() + S_SIGMA2, stop);
+    }
     HIPCHK(c, hipGetLastError());
     return VBMF_OK;
 }
@@ -1728,13 +1740,14 @@ int vbmf_sparse_set_noise_rows(vbmf_ctx* c, const double* sigmaVecHat, const dou
     std::vector<float> s32((size_t)c->Lp, 0.f);
     double mean = 0.0;
     for (int64_t l = 0; l < c->L; ++l) { s32[(size_t)l] = (float)sigmaVecHat[l]; mean += sigmaVecHat[l]; }
-    mean /= (double)c->L;
+    mean /= (double)c->Lg;                                   // this rank's share of the mean over ALL rows
     HIPCHK(c, hipMemcpy(c->sigv, sigmaVecHat, (size_t)c->L * 8, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->zetav, zetaVec, (size_t)c->L * 8, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->sig32, s32.data(), (size_t)c->Lp * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->st + c->lay.scal() + S_SIGMA2, &mean, 8, hipMemcpyHostToDevice));
     c->etaVec = etaVec;
     c->have_noise = true;
+    c->noise_mean_reduced = false;
     return VBMF_OK;
 }
 
