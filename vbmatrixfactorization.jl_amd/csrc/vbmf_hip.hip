@@ -82,6 +82,11 @@ struct vbmf_ctx {
     int64_t H1 = 0;
     bool has_mask = false;
     hipStream_t stream = nullptr;
+    // H > 128: the stand-alone control kernels (1024 threads: they cannot ride inside a 256-thread pass launch) run on a
+    // side stream beside the passes, ordered by events
+    hipStream_t side = nullptr;
+    hipEvent_t ev_main = nullptr, ev_side = nullptr;
+    bool use_side = false, side_pending = false;
     bool in_run = false;              // inside vbmf_run: the control chain rides in workgroups 0-1 of the pass launches
     int64_t ends_enqueued = 0;        // sweeps whose closing control step has been enqueued in this run (trace row)
     bool tail_pending = false;        // eig + ctrl_end of the last enqueued sweep not issued yet
@@ -205,6 +210,10 @@ static void plan_pass(Dims& d, int64_t X, int64_t K, int kstep, int NH, int Hp, 
             if (t < best * 0.999) { best = t; ns = cand; }
         }
     }
+    // H > 128: the stand-alone control kernels run beside the passes on a side stream and hold a CU each for
+    // 0.3-0.5 ms; a one-round pass then ends that much later (its last workgroup waits for the busy CU), a two-round
+    // pass of half-size workgroups just gives that CU fewer of them (measured at 100k x 10k, H = 256: 1.13 -> 0.83 ms)
+    if (want_splits <= 0 && NH == 8 && bps * ns <= NUM_CU && 2 * ns <= ks_min / (2 * kq)) ns *= 2;
     ns = (int)std::max<int64_t>(1, std::min<int64_t>(ns, std::max<int64_t>(1, ks_min / kq)));
     d.nsplit = ns;
     d.steps_per_split = (int)rup(cdiv(ks_min, d.nsplit), kq);
@@ -385,7 +394,28 @@ static int launch_gram(vbmf_ctx* c, int which, const float* cur, const float* pr
 
 static int ctrl_threads(int H) { return H <= 16 ? 64 : (H <= 32 ? 256 : 1024); }
 
-static hipStream_t ctrl_stream(vbmf_ctx* c) { return c->stream; }
+static hipStream_t ctrl_stream(vbmf_ctx* c) { return c->use_side ? c->side : c->stream; }
+// fork: what follows on ctrl_stream() runs beside the main stream, after everything enqueued on it so far;
+// end: back to the main stream; join: the main stream waits for the side section (no-op if none is pending)
+static int side_fork(vbmf_ctx* c) {
+    HIPCHK(c, hipEventRecord(c->ev_main, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_main, 0));
+    c->use_side = true;
+    return VBMF_OK;
+}
+static int side_end(vbmf_ctx* c) {
+    c->use_side = false;
+    HIPCHK(c, hipEventRecord(c->ev_side, c->side));
+    c->side_pending = true;
+    return VBMF_OK;
+}
+static int side_join(vbmf_ctx* c) {
+    if (!c->side_pending) return VBMF_OK;
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_side, 0));
+    c->side_pending = false;
+    return VBMF_OK;
+}
+static bool side_overlap(const vbmf_ctx* c) { return c->in_run && c->NH == 8; }
 
 template <int R, int T>
 static void launch_cov_t(vbmf_ctx* c, int which, hipStream_t s) {
@@ -621,6 +651,9 @@ int vbmf_destroy(vbmf_ctx* c) {
     if (c->ints_host) hipHostFree(c->ints_host);
     if (c->scal_host) hipHostFree(c->scal_host);
     if (c->stream) hipStreamDestroy(c->stream);
+    if (c->side) hipStreamDestroy(c->side);
+    if (c->ev_main) hipEventDestroy(c->ev_main);
+    if (c->ev_side) hipEventDestroy(c->ev_side);
     delete c;
     return VBMF_OK;
 }
@@ -741,6 +774,9 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
         c->err = "pinned alloc failed"; return bail(VBMF_ERR_HIP);
     }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { c->err = "stream create failed"; return bail(VBMF_ERR_HIP); }
+    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming) != hipSuccess) { c->err = "side stream create failed"; return bail(VBMF_ERR_HIP); }
     // large dynamic LDS (160 KiB per CU on gfx950) for the lambda_max kernel at 64 < H <= 128
     c->lds_limit = 160 * 1024 - 4096;
     {
@@ -1384,7 +1420,7 @@ static double digamma_host(double x) {
 template <int R, int T>
 static void launch_scov_t(vbmf_ctx* c) {
     const size_t lds = (R == 8 && T == 32) ? (size_t)(2 * 16 * GEMM_LD + 512 + 256) * sizeof(double) : (size_t)(5 * T * R) * sizeof(double);
-    hipLaunchKernelGGL((sparse_cov_b_kernel<R, T>), dim3(1), dim3(T * T), lds, c->stream, c->st, c->lay, (int)c->H, c->SB32, c->ints, c->diagvar ? 1 : 0);
+    hipLaunchKernelGGL((sparse_cov_b_kernel<R, T>), dim3(1), dim3(T * T), lds, ctrl_stream(c), c->st, c->lay, (int)c->H, c->SB32, c->ints, c->diagvar ? 1 : 0);
 }
 static int launch_sparse_cov_b(vbmf_ctx* c) {
     const int H = (int)c->H;
@@ -1422,14 +1458,15 @@ static int do_sparse_update_A(vbmf_ctx* c, bool reuse_P = false) {
         if (sharded(c)) TRY(allreduce_sum(c, c->vsq, (size_t)c->Hp, true));    // scratch, rebuilt before every use
         reuse_P = false;                            // sigma changes every iteration, so does Y' diag(sigma) B
     }
-    hipLaunchKernelGGL(sparse_v_kernel, dim3((c->Hp + 63) / 64), dim3(64), 0, c->stream, c->st, c->lay, (int)c->H, (double)c->Lg, c->vtab,
-                       c->diagvar ? (const double*)c->vsq : (const double*)nullptr, stop);
     if (!(reuse_P && c->P_valid)) {
         TRY(launch_stream(c, 0));
         const long long n = (long long)c->Hp * c->d1.XT * 32;
         hipLaunchKernelGGL(slab_sum_kernel, dim3(grid_for(n / 4, 256, 2048)), dim3(256), 0, c->stream, c->P, c->d1.nsplit, n, c->Pred, n, stop);
         if (sharded(c)) TRY(allreduce_sum(c, c->Pred, (size_t)n, false));      // Y'B summed over the row shards
     }
+    TRY(side_join(c));                              // the previous sweep's lambda_max / CB / sigma / stop test (side stream)
+    hipLaunchKernelGGL(sparse_v_kernel, dim3((c->Hp + 63) / 64), dim3(64), 0, c->stream, c->st, c->lay, (int)c->H, (double)c->Lg, c->vtab,
+                       c->diagvar ? (const double*)c->vsq : (const double*)nullptr, stop);
     const int compat = (c->o.reference_compat & VBMF_COMPAT_SPARSE_REPEAT) ? 1 : 0;
     if (compat && c->M < 2) FAIL(c, VBMF_ERR_INVALID, "repeat(v, inner=M-1) needs M >= 2");
     hipLaunchKernelGGL(sparse_update_a_kernel, dim3(grid_for((int64_t)c->M * c->Hp)), dim3(256), 0, c->stream, c->Pred,
@@ -1449,9 +1486,16 @@ static int do_sparse_update_A(vbmf_ctx* c, bool reuse_P = false) {
 
 static int do_sparse_update_B(vbmf_ctx* c) {
     TRY(ensure_gram_A(c));
-    TRY(launch_sparse_cov_b(c));
+    if (side_overlap(c)) {                          // SigmaB beside the pass: only the post kernel needs it
+        TRY(side_fork(c));
+        TRY(launch_sparse_cov_b(c));
+        TRY(side_end(c));
+    } else {
+        TRY(launch_sparse_cov_b(c));
+    }
     TRY(launch_stream(c, 1));
     TRY(fold_Q_slabs(c));
+    TRY(side_join(c));
     if (fused_gram(c) && !c->diagvar) {
         TRY(launch_post_gram(c, 1, c->Q, 1));
     } else {
@@ -1501,7 +1545,7 @@ static int sparse_update_CA(vbmf_ctx* c) {
 }
 
 static int launch_sparse_ctrl_end(vbmf_ctx* c, int flags, double eps, double* trace) {
-    hipLaunchKernelGGL(sparse_ctrl_end_kernel, dim3(1), dim3(c->H > 64 ? 1024 : 256), 0, c->stream, c->st, c->lay, (int)c->H, (double)c->Lg, flags, eps, trace, c->ints);
+    hipLaunchKernelGGL(sparse_ctrl_end_kernel, dim3(1), dim3(c->H > 64 ? 1024 : 256), 0, ctrl_stream(c), c->st, c->lay, (int)c->H, (double)c->Lg, flags, eps, trace, c->ints);
     HIPCHK(c, hipGetLastError());
     return VBMF_OK;
 }
@@ -1692,21 +1736,31 @@ int vbmf_sparse_run(vbmf_ctx* c, int64_t niter, double eps, int est_cb, int64_t*
     const int bstart = c->bcur;
     int64_t it = 0;
     bool stopped = false;
+    c->in_run = true;
     while (rc == VBMF_OK && it < niter && !stopped) {
         rc = do_sparse_update_A(c);
         if (rc == VBMF_OK) rc = do_sparse_update_B(c);
         if (rc == VBMF_OK) rc = sparse_update_CA(c);
         if (rc == VBMF_OK && c->diagvar) rc = do_hetero_sigma(c);
+        // lambda_max, CB, sigma, d and the stop test: beside the next sweep's Y'B pass when they run on the side stream
+        if (rc == VBMF_OK && side_overlap(c)) rc = side_fork(c);
         if (rc == VBMF_OK) rc = launch_eig(c, 1, 1);
         if (rc == VBMF_OK) rc = launch_sparse_ctrl_end(c, flags, eps, trace_dev);
+        if (rc == VBMF_OK && c->use_side) rc = side_end(c);
         ++it;
         if (rc == VBMF_OK && (it % 8 == 0 || it == niter)) {
+            rc = side_join(c);
+            if (rc != VBMF_OK) break;
             hipError_t e = hipMemcpyAsync(c->ints_host, c->ints, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
             if (e != hipSuccess) { c->err = std::string("sparse run sync: ") + hipGetErrorString(e); rc = VBMF_ERR_HIP; break; }
             if (c->ints_host[I_STOP] || c->ints_host[I_ERR]) stopped = true;
         }
     }
+    c->in_run = false;
+    c->use_side = false;
+    c->side_pending = false;
+    hipStreamSynchronize(c->side);
     hipStreamSynchronize(c->stream);
     if (rc == VBMF_OK) {
         hipError_t e = hipMemcpy(c->ints_host, c->ints, 4 * sizeof(int), hipMemcpyDeviceToHost);
