@@ -368,3 +368,30 @@ def test_logged_trajectory_against_the_reference_record(pkg, golden_dir, tmp_pat
     worst["sigma2"] = float(np.max(np.abs(log["sigma2"] - ref["sigma2"]) / ref["sigma2"]))
     report("logged trajectory vs the reference's recorded log, worst slice: " + " ".join(f"{k}={v:.2e}" for k, v in worst.items()))
     assert max(worst.values()) < 2e-3, worst
+
+
+def test_rank_above_128_loop_and_termination(pkg):
+    """H > 128 inside vbmf_run: the 1024-thread control kernels run on a side stream beside the passes (events order
+    SigmaA / SigmaB before the post kernels, lambda_max + ctrl_end beside the next sweep's Y'B).  The loop must stop at
+    the oracle's sweep and leave the state frozen there."""
+    L, M, H = 700, 520, 130
+    Y, po = _problem(L, M, H, 4321, separated=True)
+    ydt, fdt, tol = _mode_opts(pkg, "bf16x2")
+    Ys = _stored(pkg, Y, H, ydt, fdt)
+    pkg.set_defaults(y_dtype=ydt, factor_dtype=fdt)
+    # an eps well inside a gap of the oracle's d sequence (lambda_max at H > 128 is a fixed-count power iteration, good to
+    # ~1e-3: a threshold within a percent of some d_k would make the stopping sweep a coin toss)
+    probe = clone_oracle(po)
+    tr = []
+    O.vbmf_(Ys, probe, 16, eps=0.0, est_covs=True, est_var=True, trace=tr)
+    ds = np.array([t[0] for t in tr])
+    k = 5 + int(np.argmax(ds[5:12] / ds[6:13]))              # widest ratio between consecutive sweeps 6..13
+    eps = float(np.sqrt(ds[k] * ds[k + 1]))
+    assert ds[k] > 1.05 * eps > 1.05 * 1.05 * ds[k + 1] or ds[k] / ds[k + 1] > 1.1
+    pg = to_pkg_params(pkg, po)
+    pkg.vbmf_(Ys, pg, 40, eps=eps, est_covs=True, est_var=True)
+    _, n, d = O.vbmf_(Ys, po, 40, eps=eps, est_covs=True, est_var=True)
+    report(f"H=130 termination (eps={eps:.3e}): oracle n={n} d={d:.3e}; gpu n={pg._last_run[0]} d={pg._last_run[1]:.3e}")
+    assert n == k + 2 and pg._last_run[0] == n
+    compare("bf16x2 700x520 H130 run-to-stop", pg, po, {k_: 10 * v for k_, v in tol.items()})
+    assert abs(pg._last_run[1] - d) <= 3e-2 * d + D_ATOL

@@ -516,6 +516,12 @@ static int do_update_A(vbmf_ctx* c, bool reuse_P = false) {
         // SigmaA was computed speculatively beside the previous sweep's stop test: commit it iff the loop continues
         hipLaunchKernelGGL(commit_cov_a_kernel, dim3(8), dim3(256), 0, c->stream, c->st, c->lay, c->ints);
         HIPCHK(c, hipGetLastError());
+    } else if (side_overlap(c)) {
+        // H > 128: SigmaA (after the previous sweep's lambda_max / ctrl_end, already on the side stream) beside the pass
+        TRY(side_fork(c));
+        TRY(launch_ctrl_cov(c, 0));
+        TRY(side_end(c));
+        TRY(launch_stream(c, 0));
     } else {
         TRY(launch_ctrl_cov(c, 0));
         TRY(launch_stream(c, 0));
@@ -529,9 +535,11 @@ static int do_update_A(vbmf_ctx* c, bool reuse_P = false) {
             if (sharded(c))
                 TRY(allreduce_sum(c, c->Pred, (size_t)n, false));
         }
+        TRY(side_join(c));
         if (fused_gram(c)) TRY(launch_post_gram(c, 0, c->Pred, 1));
         else TRY(launch_post(c, 0, c->Pred, 1));
     } else {
+        TRY(side_join(c));
         if (fused_gram(c)) TRY(launch_post_gram(c, 0, c->P, 1));
         else TRY(launch_post(c, 0, c->P, 1));
     }
@@ -557,11 +565,17 @@ static int do_update_B(vbmf_ctx* c) {
     TRY(ensure_gram_A(c));
     if (fused_ctrl(c)) {
         TRY(launch_stream(c, 1, CTRL_COV_B | CTRL_EIG_BOLD));
+    } else if (side_overlap(c)) {
+        TRY(side_fork(c));
+        TRY(launch_ctrl_cov(c, 1));
+        TRY(side_end(c));
+        TRY(launch_stream(c, 1));
     } else {
         TRY(launch_ctrl_cov(c, 1));
         TRY(launch_stream(c, 1));
     }
     TRY(fold_Q_slabs(c));
+    TRY(side_join(c));
     if (fused_gram(c)) {
         TRY(launch_post_gram(c, 1, c->Q, 1));
     } else {
@@ -1200,10 +1214,14 @@ int vbmf_run(vbmf_ctx* c, int64_t niter, double eps, int est_covs, int est_var, 
                 if (rc == VBMF_OK) rc = launch_ctrl_end(c, flags | 32, eps, trace_dev);
                 ++c->ends_enqueued;
             } else {
-                rc = launch_eig(c, 1, 1);
+                // H > 128: beside the next sweep's Y'B pass (side stream); the checkpoint below joins first
+                if (side_overlap(c)) rc = side_fork(c);
+                if (rc == VBMF_OK) rc = launch_eig(c, 1, 1);
                 if (rc == VBMF_OK) rc = launch_ctrl_end(c, flags, eps, trace_dev);
+                if (rc == VBMF_OK && c->use_side) rc = side_end(c);
             }
         }
+        if (rc == VBMF_OK && checkpoint) rc = side_join(c);
         if (rc == VBMF_OK && checkpoint) {
             hipError_t e = hipMemcpyAsync(c->ints_host, c->ints, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -1214,6 +1232,9 @@ int vbmf_run(vbmf_ctx* c, int64_t niter, double eps, int est_covs, int est_var, 
     c->in_run = false;
     c->tail_pending = false;
     c->run_trace = nullptr;
+    c->use_side = false;
+    c->side_pending = false;
+    hipStreamSynchronize(c->side);
     hipStreamSynchronize(c->stream);
     if (rc == VBMF_OK) {
         hipError_t e = hipMemcpyAsync(c->ints_host, c->ints, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
