@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--factor", default="auto", choices=["auto", "bf16", "bf16x2"])
     ap.add_argument("--splits", type=int, default=0, help="split-K of the Y'B pass (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--event-stride", type=int, default=4,
+                    help="HIP events bracket every k-th launch of each pass inside the timed region (each timed launch "
+                         "costs two event packets on the stream; 1 = every launch)")
     ap.add_argument("--shard-of", type=int, default=0,
                     help="developer aid on ONE GPU: run rank 0's share of an N-rank strong-scaling job (L/N rows, "
                          "L_global = L, 1-rank communicator => the collective code path); an upper bound for N GPUs")
@@ -168,7 +171,7 @@ def main():
 
     if a.warmup > 0:
         run(a.warmup)
-    ctx.profile_enable(True)
+    ctx.profile_enable(max(1, a.event_stride))
     barrier()
     t0 = time.perf_counter()
     it, d, _ = run(a.steps)
@@ -229,7 +232,8 @@ def main():
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "kernel": "stream_gemm_kernel (pass 1: Y'B, pass 2: Y*A; this rank's shard)",
-            "bytes_per_launch": avg_bytes, "avg_launch_ms": avg_ms, "launches": n,
+            "bytes_per_launch": avg_bytes, "avg_launch_ms": avg_ms, "launches_timed": n,
+            "launches": 2 * a.steps, "event_stride": max(1, a.event_stride),
             "pass1": {"ms": prof["pass1_ms"] / max(prof["pass1_n"], 1), "bytes": bytes1,
                       "GBps": bytes1 / max(prof["pass1_ms"] / max(prof["pass1_n"], 1), 1e-9) / 1e6},
             "pass2": {"ms": prof["pass2_ms"] / max(prof["pass2_n"], 1), "bytes": bytes2,

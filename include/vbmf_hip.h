@@ -193,7 +193,8 @@ typedef int (*vbmf_allreduce_fn)(void* user, void* buf, size_t count, int is_dou
 int vbmf_comm_set_transport(vbmf_ctx* ctx, vbmf_allreduce_fn fn, void* user);
 
 /* ---- measurement hooks (bench.py): HIP-event timing of the two streaming kernels ---- */
-int vbmf_profile_enable(vbmf_ctx* ctx, int on);
+int vbmf_profile_enable(vbmf_ctx* ctx, int on);   /* 0: off; k > 0: time every k-th launch of each pass (the probe costs two
+                                                     * event packets per timed launch, so a stride keeps it out of the throughput) */
 /* out[0]=ms in Y'B pass, out[1]=launches, out[2]=ms in Y*A pass, out[3]=launches, out[4..7] reserved */
 int vbmf_profile_read(vbmf_ctx* ctx, double* out8, int reset);
 /* algorithmic bytes one launch of pass p (1|2) moves: Y once + factor in + result out */

@@ -383,10 +383,19 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restric
 // the split-K partials of the Y'B pass (nsplit x 2.5 MB at 10k x 64) are folded here at HBM/L2 rate
 // instead of inside the 80-block post kernel.  n must be a multiple of 4 (it is: Hp * Xp).
 // out may be slab 0 itself (element-wise: every thread reads its element of all slabs, then writes it).
+// An optional stop-gated side job rides along (saves a launch per sweep): copy cp_n doubles cp_src -> cp_dst and one
+// more double sc_src -> sc_dst -- the commit of the speculative SigmaA (ctrl_kernels.hpp, ctrl_chain).
+struct SideCopy { const double* cp_src; double* cp_dst; long long cp_n; const double* sc_src; double* sc_dst; };
 __global__ __launch_bounds__(256) void slab_sum_kernel(const float* slabs, int nslab,
                                                        long long slabStride, float* out, long long n,
-                                                       const int* __restrict__ stop) {
+                                                       const int* __restrict__ stop, SideCopy side) {
     if (stop && *stop) return;
+    const int nb = gridDim.x < 8 ? (int)gridDim.x : 8;
+    if (side.cp_n > 0 && (int)blockIdx.x < nb) {
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < side.cp_n; i += (long long)nb * blockDim.x)
+            side.cp_dst[i] = side.cp_src[i];
+        if (blockIdx.x == 0 && threadIdx.x == 0 && side.sc_src) *side.sc_dst = *side.sc_src;
+    }
     const long long n4 = n >> 2;
     const float4* in4 = reinterpret_cast<const float4*>(slabs);
     float4* out4 = reinterpret_cast<float4*>(out);

@@ -97,7 +97,9 @@ struct vbmf_ctx {
     bool gA_valid = false, gB_valid = false, P_valid = false, kb_identity = false;
     double trYY_local = 0.0;
     bool trYY_reduced = true;
-    bool prof = false;
+    int prof = 0;                     // 0 off; k: HIP events around every k-th launch of each pass
+    bool prof_skip = true;
+    long long prof_seen[2] = {0, 0};
     std::vector<ProfEvent> pev;
     double prof_ms[2] = {0, 0};
     double prof_n[2] = {0, 0};
@@ -222,7 +224,10 @@ static void plan_pass(Dims& d, int64_t X, int64_t K, int kstep, int NH, int Hp, 
 
 // ------------------------------------------------------------------------------------------------
 static void prof_begin(vbmf_ctx* c, int pass) {
+    c->prof_skip = true;
     if (!c->prof) return;
+    if ((c->prof_seen[pass]++ % c->prof) != 0) return;       // every prof-th launch of each pass is timed
+    c->prof_skip = false;
     ProfEvent e{};
     e.pass = pass;
     hipEventCreate(&e.a);
@@ -231,7 +236,7 @@ static void prof_begin(vbmf_ctx* c, int pass) {
     c->pev.push_back(e);
 }
 static void prof_end(vbmf_ctx* c) {
-    if (!c->prof) return;
+    if (!c->prof || c->prof_skip) return;
     hipEventRecord(c->pev.back().b, c->stream);
 }
 static void prof_harvest(vbmf_ctx* c) {
@@ -507,6 +512,7 @@ static int ensure_gram_B(vbmf_ctx* c) {
 static int do_update_A(vbmf_ctx* c, bool reuse_P = false) {
     TRY(ensure_gram_B(c));
     const bool have_P = reuse_P && c->P_valid;
+    bool commit_pending = false;
     if (have_P) {
         TRY(launch_ctrl_cov(c, 0));
     } else if (fused_ctrl(c)) {
@@ -514,8 +520,13 @@ static int do_update_A(vbmf_ctx* c, bool reuse_P = false) {
         if (c->tail_pending) ++c->ends_enqueued;
         c->tail_pending = false;
         // SigmaA was computed speculatively beside the previous sweep's stop test: commit it iff the loop continues
-        hipLaunchKernelGGL(commit_cov_a_kernel, dim3(8), dim3(256), 0, c->stream, c->st, c->lay, c->ints);
-        HIPCHK(c, hipGetLastError());
+        // (inside the slab-sum launch when there is one, else as its own small kernel)
+        commit_pending = true;
+        if (!(sharded(c) || c->d1.nsplit > 1)) {
+            hipLaunchKernelGGL(commit_cov_a_kernel, dim3(8), dim3(256), 0, c->stream, c->st, c->lay, c->ints);
+            HIPCHK(c, hipGetLastError());
+            commit_pending = false;
+        }
     } else if (side_overlap(c)) {
         // H > 128: SigmaA (after the previous sweep's lambda_max / ctrl_end, already on the side stream) beside the pass
         TRY(side_fork(c));
@@ -529,8 +540,12 @@ static int do_update_A(vbmf_ctx* c, bool reuse_P = false) {
     if (sharded(c) || c->d1.nsplit > 1) {
         const long long n = (long long)c->Hp * c->d1.XT * 32;
         if (!have_P) {
+            SideCopy sc{};
+            if (commit_pending)
+                sc = SideCopy{c->st + c->lay.W0(), c->st + c->lay.SA(), c->lay.n2(), c->st + c->lay.scal() + S_LOGDET_SA_SHADOW,
+                              c->st + c->lay.scal() + S_LOGDET_SA};
             hipLaunchKernelGGL(slab_sum_kernel, dim3(grid_for(n / 4, 256, 2048)), dim3(256), 0, c->stream, c->P, c->d1.nsplit, n,
-                               c->Pred, n, c->ints + I_STOP);
+                               c->Pred, n, c->ints + I_STOP, sc);
             HIPCHK(c, hipGetLastError());
             if (sharded(c))
                 TRY(allreduce_sum(c, c->Pred, (size_t)n, false));
@@ -556,7 +571,7 @@ static int fold_Q_slabs(vbmf_ctx* c) {
     if (c->d2.nsplit <= 1) return VBMF_OK;
     const long long n = (long long)c->Hp * c->d2.XT * 32;
     hipLaunchKernelGGL(slab_sum_kernel, dim3(grid_for(n / 4, 256, 2048)), dim3(256), 0, c->stream, c->Q, c->d2.nsplit, n, c->Q, n,
-                       c->ints + I_STOP);
+                       c->ints + I_STOP, SideCopy{});
     HIPCHK(c, hipGetLastError());
     return VBMF_OK;
 }
@@ -1339,7 +1354,8 @@ int vbmf_profile_enable(vbmf_ctx* c, int on) {
     if (!c) return VBMF_ERR_INVALID;
     hipSetDevice(c->o.device);
     prof_harvest(c);
-    c->prof = on != 0;
+    c->prof = on > 0 ? on : 0;
+    c->prof_seen[0] = c->prof_seen[1] = 0;
     return VBMF_OK;
 }
 
@@ -1399,8 +1415,8 @@ int vbmf_debug_time_pass(vbmf_ctx* c, int pass, int iters, double* ms) {
     hipEvent_t a, b;
     HIPCHK(c, hipEventCreate(&a));
     HIPCHK(c, hipEventCreate(&b));
-    const bool prof = c->prof;
-    c->prof = false;
+    const int prof = c->prof;
+    c->prof = 0;
     int rc = launch_stream(c, pass - 1);
     if (rc == VBMF_OK) rc = launch_stream(c, pass - 1);
     hipEventRecord(a, c->stream);
@@ -1482,7 +1498,7 @@ static int do_sparse_update_A(vbmf_ctx* c, bool reuse_P = false) {
     if (!(reuse_P && c->P_valid)) {
         TRY(launch_stream(c, 0));
         const long long n = (long long)c->Hp * c->d1.XT * 32;
-        hipLaunchKernelGGL(slab_sum_kernel, dim3(grid_for(n / 4, 256, 2048)), dim3(256), 0, c->stream, c->P, c->d1.nsplit, n, c->Pred, n, stop);
+        hipLaunchKernelGGL(slab_sum_kernel, dim3(grid_for(n / 4, 256, 2048)), dim3(256), 0, c->stream, c->P, c->d1.nsplit, n, c->Pred, n, stop, SideCopy{});
         if (sharded(c)) TRY(allreduce_sum(c, c->Pred, (size_t)n, false));      // Y'B summed over the row shards
     }
     TRY(side_join(c));                              // the previous sweep's lambda_max / CB / sigma / stop test (side stream)
