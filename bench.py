@@ -231,7 +231,8 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "kernel": "stream_gemm_kernel (pass 1: Y'B, pass 2: Y*A; this rank's shard)",
+            "kernel": "stream_gemm_kernel (pass 1: Y'B; pass 2: Y*A, at H <= 64 with the B update + Gram partials as its "
+                      "register epilogue; this rank's shard)",
             "bytes_per_launch": avg_bytes, "avg_launch_ms": avg_ms, "launches_timed": n,
             "launches": 2 * a.steps, "event_stride": max(1, a.event_stride),
             "pass1": {"ms": prof["pass1_ms"] / max(prof["pass1_n"], 1), "bytes": bytes1,

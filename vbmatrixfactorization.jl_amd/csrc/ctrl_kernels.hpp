@@ -36,7 +36,7 @@ struct StateLayout {
 enum : int { S_SIGMA2 = 0, S_TRYY, S_LOGDET_SA, S_LOGDET_SB, S_LAMB_PREV, S_LAMB_NEW, S_LAMD, S_D, S_ELBO,
              S_TRDOT, S_RESID, S_TRYBA,
              S_LOGDET_SA_SHADOW = 20 };      // 12..18: sparse_kernels.hpp
-enum : int { I_STOP = 0, I_ITERS = 1, I_ERR = 2, I_NITER = 3 };
+enum : int { I_STOP = 0, I_ITERS = 1, I_ERR = 2, I_NITER = 3, I_SREADY = 4 };
 
 __device__ __forceinline__ double block_sum(double v, double* red) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
@@ -648,6 +648,7 @@ struct CtrlArgs {
     int H, spectral, end_flags;
     int mode;              // CTRL_* bits; 0: no control workgroups in this launch
     int it_row;            // sweep index (trace row) the CTRL_PREV_END part finalises
+    int* sready; int sready_val;   // release flag for the Sigma table of part 0 (the pass's register epilogue waits on it)
 };
 // Schedule inside vbmf_run (sweep j; B_{j-1} is the factor the sweep starts from):
 //   pass 1 of sweep j : [lambda_max(dB'dB) of sweep j-1, ctrl_end of sweep j-1]  then  SigmaA of sweep j
@@ -688,6 +689,11 @@ __device__ __forceinline__ void ctrl_chain(const CtrlArgs& a, void* lds, int par
         if (a.mode & CTRL_COV_A)
             ctrl_cov_dev<R, 16>(a.st, a.lay, a.H, 0, a.Lg, a.S32, a.ints, reinterpret_cast<double*>(lds), true);
         if (a.mode & CTRL_COV_B) ctrl_cov_dev<R, 16>(a.st, a.lay, a.H, 1, a.M, a.S32, a.ints, reinterpret_cast<double*>(lds));
+        if (a.sready) {                                     // set unconditionally: a waiting epilogue must never hang
+            __threadfence();
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_store(a.sready, a.sready_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
     } else {
         if (a.mode & CTRL_PREV_END) {
             eig_dev<R>(a.st, a.lay, a.H, a.spectral, 0, a.ints, reinterpret_cast<float*>(lds), S_LAMD);

@@ -115,6 +115,56 @@ __global__ __launch_bounds__(256) void post_kernel(const float* __restrict__ In,
     }
 }
 
+// ---- one 32-row tile of "post + Gram" from a product tile that is still in accumulator registers --------------
+// q[hin][r] on lane (half, c) holds (Y A)[x0 + c][hin*32 + rho(r, half)] -- the streaming kernel's accumulator as it
+// stands.  An exact-f32 MFMA of k = 2 takes its two k values from the two lane halves, and the contraction may run in
+// any k order as long as both operands agree, so register r IS the A operand of instruction r when the table operand
+// is read in the same permuted order: sperm[hin][r][h] = S[hin*32 + rho(r, half)][h*32 + c].  No store, no reload,
+// no shuffle between the product and the update B = (Y A) SigmaB / sigma2 (src/vbmf.jl:112).
+template <int MODE, int NH>
+__device__ __forceinline__ void post_gram_tile_regs(const f32x16 (&q)[NH], const float (&sperm)[NH][16][NH], int xt,
+                                                    float* __restrict__ Fac, const float* __restrict__ Prev,
+                                                    uint4* __restrict__ Ft, int lane,
+                                                    f32x16 (&G)[NH * (NH + 1) / 2], f32x16 (&D)[NH * (NH + 1) / 2],
+                                                    const f32x16 (&pv)[NH]) {
+    constexpr int Hp = NH * 32;
+    const int c = lane & 31, half = lane >> 5;
+    const long long x0 = (long long)xt * 32;
+    (void)Prev;
+    f32x16 acc[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[h][r] = 0.f;
+#pragma unroll
+    for (int hin = 0; hin < NH; ++hin)
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                const float a = q[hin][t];
+                acc[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, sperm[hin][t][h], acc[h], 0, 0, 0);
+            }
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        write_factor_tiles<MODE, NH>(Ft, acc[h], xt, h, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Fac[(x0 + rho(r, half)) * Hp + h * 32 + c] = acc[h][r];
+    }
+    int p = 0;
+#pragma unroll
+    for (int h1 = 0; h1 < NH; ++h1)
+#pragma unroll
+        for (int h2 = h1; h2 < NH; ++h2, ++p)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float u = acc[h1][r], v = acc[h2][r];
+                G[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(u, v, G[p], 0, 0, 0);
+                const float du = pv[h1][r] - u, dv = pv[h2][r] - v;
+                D[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(du, dv, D[p], 0, 0, 0);
+            }
+}
+
 // ---- fused post + Gram (NH <= 2) ---------------------------------------------------------------------
 // Same update as post_kernel, and while the new 32-row tile still sits in accumulator registers its
 // Gram contribution (and, against the previous factor, the delta-Gram) is added with the tile fed back

@@ -36,20 +36,31 @@
 #pragma once
 #include "common.hpp"
 #include "ctrl_kernels.hpp"
+#include "post_kernels.hpp"
 
 namespace vbmf {
 
 // cache policy of the Y stream: 2 = nt (streamed once); 0 = default
 constexpr int Y_AUX = 2;
 
+// Epilogue of the Y*A pass (EPI = 1, un-split pass, H <= 64): the product tiles never leave the registers -- B = (Y A) SigmaB
+// / sigma2, its operand tiles, the fp32 factor and the Gram / delta-Gram partials are produced right here
+// (post_kernels.hpp, post_gram_tile_regs), which removes the L x H round trip through HBM and one launch per sweep.
+// SigmaB is computed by control workgroup 0 of this very launch: `sready` is its release flag.
+struct EpiArgs {
+    const float* S; float* Fac; const float* Prev; uint4* Ft; float* slabs;
+    const int* sready; int expect;           // expect < 0: the table was complete before the launch
+    int* err;
+};
+
 // FDBG (tuning harness only): 1 = the factor ring re-reads one L1-hot k-step, 2 = no factor refills at all
-template <int MODE, int NH, int NXW_, int DY, int DF, int RCTRL, int FDBG = 0>
+template <int MODE, int NH, int NXW_, int DY, int DF, int RCTRL, int FDBG = 0, int EPI = 0>
 __global__ __launch_bounds__(256) void stream_gemm_kernel(const uint4* __restrict__ Yt,   // [XT][KS][64]
                                                           const uint4* __restrict__ Ft,   // [KS][NPART][NH][64]
                                                           float* __restrict__ Out,        // [nsplit][NH*32][ldOut]
                                                           int XG, int KS, int steps_per_split, int nsplit,
                                                           long long ldOut, const int* __restrict__ stop,
-                                                          CtrlArgs ctrl, int xcd_xb) {
+                                                          CtrlArgs ctrl, int xcd_xb, EpiArgs epi = EpiArgs{}) {
     constexpr int NPART = ModeTraits<MODE>::NPART;
     constexpr int NF = NPART * NH;
     static_assert(PIPE_D % DY == 0 && DY % DF == 0, "ring depths must divide the padding quantum");
@@ -83,8 +94,16 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const uint4* __restric
         split = bid / bps;
         xb = bid % bps;
     }
-    const int xg = xb * 4 + wib;
-    if (xg >= XG || split >= nsplit) return;              // wave-uniform
+    int xg = xb * 4 + wib;
+    bool active = true;
+    if constexpr (EPI) {
+        // every wave of the workgroup meets in the epilogue's fold: a wave without an x group streams nothing
+        if (split >= nsplit) return;                       // workgroup-uniform
+        active = xg < XG;
+        if (!active) { xg = 0; steps_per_split = -DY; }
+    } else {
+        if (xg >= XG || split >= nsplit) return;          // wave-uniform
+    }
 
     const long long ks0 = (long long)split * steps_per_split;
     const unsigned ybytes = (unsigned)steps_per_split * 1024u;
@@ -202,15 +221,76 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const uint4* __restric
         }
     }
 
-    const int c = lane & 31, half = lane >> 5;
-    float* o = Out + (long long)split * (NH * 32) * ldOut;
+    if constexpr (EPI) {
+        static_assert(EPI == 0 || NH <= 2, "register epilogue keeps NH(NH+1)/2 pair tiles per Gram");
+        constexpr int NPAIR = NH * (NH + 1) / 2;
+        constexpr int Hp = NH * 32;
+        __shared__ float fold[2 * NPAIR * 16 * 64];
+        const int c = lane & 31, half = lane >> 5;
+        if (epi.expect >= 0) {                             // SigmaB / sigma2 is written by workgroup 0 of this launch
+            int spins = 0;
+            while (__hip_atomic_load(epi.sready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epi.expect) {
+                __builtin_amdgcn_s_sleep(16);
+                if (++spins > (1 << 22)) { if (lane == 0) atomicExch(epi.err, 2); break; }    // never hang the device
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        float sperm[NH][16][NH];
 #pragma unroll
-    for (int i = 0; i < NXW_; ++i) {
-        const long long x = (long long)(xg * NXW_ + i) * 32 + c;
+        for (int hin = 0; hin < NH; ++hin)
 #pragma unroll
-        for (int h = 0; h < NH; ++h)
+            for (int t = 0; t < 16; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[(long long)(h * 32 + rho(r, half)) * ldOut + x] = acc[i][h][r];
+                for (int h = 0; h < NH; ++h)
+                    sperm[hin][t][h] = epi.S[(long long)(hin * 32 + rho(t, half)) * Hp + h * 32 + c];
+        f32x16 G[NPAIR], D[NPAIR];
+#pragma unroll
+        for (int p = 0; p < NPAIR; ++p)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { G[p][r] = 0.f; D[p][r] = 0.f; }
+        if (active) {
+            // the previous factor's rows of all this wave's tiles first (they are only needed for the delta-Gram at the
+            // end of each tile: one round of memory latency instead of one per tile)
+            f32x16 pv[NXW_][NH];
+#pragma unroll
+            for (int i = 0; i < NXW_; ++i)
+#pragma unroll
+                for (int h = 0; h < NH; ++h)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        pv[i][h][r] = epi.Prev[((long long)(xg * NXW_ + i) * 32 + rho(r, half)) * Hp + h * 32 + c];
+#pragma unroll
+            for (int i = 0; i < NXW_; ++i)
+                post_gram_tile_regs<MODE, NH>(acc[i], sperm, xg * NXW_ + i, epi.Fac, epi.Prev, epi.Ft, lane, G, D, pv[i]);
+        }
+        // fold the four waves' partials (fixed order => deterministic), then one coalesced slab store per workgroup
+        for (int wv = 0; wv < 4; ++wv) {
+            if (wib == wv) {
+#pragma unroll
+                for (int p = 0; p < NPAIR; ++p)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ig = (p * 16 + r) * 64 + lane, id = ((NPAIR + p) * 16 + r) * 64 + lane;
+                        const float g = G[p][r], d = D[p][r];
+                        if (wv == 0) { fold[ig] = g; fold[id] = d; }
+                        else { fold[ig] += g; fold[id] += d; }
+                    }
+            }
+            __syncthreads();
+        }
+        float* o = epi.slabs + (long long)xb * (2 * NPAIR * 1024);
+        for (int i = threadIdx.x; i < 2 * NPAIR * 1024; i += 256) o[i] = fold[i];
+    } else {
+        const int c = lane & 31, half = lane >> 5;
+        float* o = Out + (long long)split * (NH * 32) * ldOut;
+    #pragma unroll
+        for (int i = 0; i < NXW_; ++i) {
+            const long long x = (long long)(xg * NXW_ + i) * 32 + c;
+    #pragma unroll
+            for (int h = 0; h < NH; ++h)
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) o[(long long)(h * 32 + rho(r, half)) * ldOut + x] = acc[i][h][r];
+        }
     }
 }
 

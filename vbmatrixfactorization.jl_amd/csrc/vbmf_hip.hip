@@ -88,6 +88,8 @@ struct vbmf_ctx {
     hipEvent_t ev_main = nullptr, ev_side = nullptr;
     bool use_side = false, side_pending = false;
     bool in_run = false;              // inside vbmf_run: the control chain rides in workgroups 0-1 of the pass launches
+    int gslab_cap = 256;
+    int sready_seq = 0;               // sequence number of the Sigma-table release flag (register epilogue)
     int64_t ends_enqueued = 0;        // sweeps whose closing control step has been enqueued in this run (trace row)
     bool tail_pending = false;        // eig + ctrl_end of the last enqueued sweep not issued yet
     int run_flags = 0;
@@ -261,7 +263,9 @@ static size_t ctrl_lds_bytes(int NH) {
 static bool fused_ctrl(const vbmf_ctx* c) { return c->in_run && c->NH <= 4; }
 
 // ctrl_mode != 0: workgroup 0 of the launch runs that part of the control chain (CtrlArgs)
-static int launch_stream(vbmf_ctx* c, int pass, int ctrl_mode = 0) {
+// epi (pass 2 only, un-split, NH <= 2): B, its operand tiles and the Gram partials are produced in the kernel's register
+// epilogue (no separate post kernel); the caller then only reduces c->gslab over `*epi_slabs` workgroup slabs
+static int launch_stream(vbmf_ctx* c, int pass, int ctrl_mode = 0, bool epi = false, int* epi_slabs = nullptr) {
     const Dims& d = pass == 0 ? c->d1 : c->d2;
     const uint4* Y = pass == 0 ? c->Y1 : c->Y2;
     const uint4* F = pass == 0 ? (c->diagvar ? c->FBs : c->FB) : c->FA;
@@ -276,13 +280,35 @@ static int launch_stream(vbmf_ctx* c, int pass, int ctrl_mode = 0) {
     ca.Lg = (double)c->Lg; ca.M = (double)c->M; ca.eps = c->run_eps;
     ca.H = (int)c->H; ca.spectral = (c->o.reference_compat & VBMF_COMPAT_SPECTRAL_DELTA) ? 1 : 0;
     ca.end_flags = c->run_flags; ca.mode = ctrl_mode; ca.it_row = (int)c->ends_enqueued;
+    EpiArgs ea{};
+    if (epi) {
+        c->sready_seq = (c->sready_seq + 1) & 0x3fffffff;
+        ea.S = c->SB32; ea.Fac = c->B32[c->bcur ^ 1]; ea.Prev = c->B32[c->bcur]; ea.Ft = c->FB; ea.slabs = c->gslab;
+        ea.sready = c->ints + I_SREADY; ea.expect = ctrl_mode ? c->sready_seq : -1; ea.err = c->ints + I_ERR;
+        if (ctrl_mode) { ca.sready = c->ints + I_SREADY; ca.sready_val = c->sready_seq; }
+        if (epi_slabs) *epi_slabs = bps;
+    }
     const size_t lds = ctrl_mode ? ctrl_lds_bytes(c->NH) : 0;
     prof_begin(c, pass);
-    DISPATCH_MODE(c->mode, DISPATCH_NH(c->NH, {
-        using Cfg = StreamCfg<NHc>;
-        hipLaunchKernelGGL((stream_gemm_kernel<MODEc, NHc, Cfg::NXWc, Cfg::DYc, Cfg::DFc, Cfg::Rc>), dim3(grid), dim3(256), lds,
-                           c->stream, Y, F, out, XG, d.KS, d.steps_per_split, d.nsplit, ld, c->ints + I_STOP, ca, 0);
-    }));
+    if (epi) {
+        DISPATCH_MODE(c->mode, {
+            if (c->NH == 1) {
+                using Cfg = StreamCfg<1>;
+                hipLaunchKernelGGL((stream_gemm_kernel<MODEc, 1, Cfg::NXWc, Cfg::DYc, Cfg::DFc, Cfg::Rc, 0, 1>), dim3(grid), dim3(256), lds,
+                                   c->stream, Y, F, out, XG, d.KS, d.steps_per_split, d.nsplit, ld, c->ints + I_STOP, ca, 0, ea);
+            } else {
+                using Cfg = StreamCfg<2>;
+                hipLaunchKernelGGL((stream_gemm_kernel<MODEc, 2, Cfg::NXWc, Cfg::DYc, Cfg::DFc, Cfg::Rc, 0, 1>), dim3(grid), dim3(256), lds,
+                                   c->stream, Y, F, out, XG, d.KS, d.steps_per_split, d.nsplit, ld, c->ints + I_STOP, ca, 0, ea);
+            }
+        });
+    } else {
+        DISPATCH_MODE(c->mode, DISPATCH_NH(c->NH, {
+            using Cfg = StreamCfg<NHc>;
+            hipLaunchKernelGGL((stream_gemm_kernel<MODEc, NHc, Cfg::NXWc, Cfg::DYc, Cfg::DFc, Cfg::Rc>), dim3(grid), dim3(256), lds,
+                               c->stream, Y, F, out, XG, d.KS, d.steps_per_split, d.nsplit, ld, c->ints + I_STOP, ca, 0);
+        }));
+    }
     prof_end(c);
     HIPCHK(c, hipGetLastError());
     return VBMF_OK;
@@ -320,6 +346,7 @@ static int launch_post(vbmf_ctx* c, int which, const float* In, int nslab) {
 // fused post + Gram (+ delta-Gram) for NH <= 2; reduction into the state block (or the all-reduce staging)
 static bool fused_gram(const vbmf_ctx* c) { return c->NH <= 2; }
 
+static int launch_pair_reduce(vbmf_ctx* c, int which, int nslab);
 static int launch_post_gram(vbmf_ctx* c, int which, const float* In, int nslab) {
     const Dims& d = which == 0 ? c->d1 : c->d2;
     const long long ld = (long long)d.XT * 32;
@@ -336,12 +363,18 @@ static int launch_post_gram(vbmf_ctx* c, int which, const float* In, int nslab) 
         if (c->NH == 1) hipLaunchKernelGGL((post_gram_kernel<MODEc, 1>), dim3(grid), dim3(256), 0, c->stream, In, ld, nslab, slabStride, S, Fac, Prev, Ft, mk, hstart, d.XT, c->gslab, stop);
         else hipLaunchKernelGGL((post_gram_kernel<MODEc, 2>), dim3(grid), dim3(256), 0, c->stream, In, ld, nslab, slabStride, S, Fac, Prev, Ft, mk, hstart, d.XT, c->gslab, stop);
     });
+    return launch_pair_reduce(c, which, grid);
+}
+
+// fp64 reduction of `nslab` workgroup slabs of Gram partials in c->gslab into the state (all-reduced when row-sharded)
+static int launch_pair_reduce(vbmf_ctx* c, int which, int nslab) {
+    const int* stop = c->ints + I_STOP;
     const int n = c->Hp * c->Hp;
     const bool shard = (which == 1 && sharded(c));
     double* outG = shard ? c->gtmp : c->st + (which == 0 ? c->lay.GA() : c->lay.GB());
     double* outD = which == 0 ? nullptr : (shard ? c->gtmp + n : c->st + c->lay.GD());
-    if (c->NH == 1) hipLaunchKernelGGL((pair_slab_reduce_kernel<1>), dim3(2 * 1 * 1024 / 64), dim3(1024), 0, c->stream, c->gslab, grid, outG, outD, stop);
-    else hipLaunchKernelGGL((pair_slab_reduce_kernel<2>), dim3(2 * 3 * 1024 / 64), dim3(1024), 0, c->stream, c->gslab, grid, outG, outD, stop);
+    if (c->NH == 1) hipLaunchKernelGGL((pair_slab_reduce_kernel<1>), dim3(2 * 1 * 1024 / 64), dim3(1024), 0, c->stream, c->gslab, nslab, outG, outD, stop);
+    else hipLaunchKernelGGL((pair_slab_reduce_kernel<2>), dim3(2 * 3 * 1024 / 64), dim3(1024), 0, c->stream, c->gslab, nslab, outG, outD, stop);
     HIPCHK(c, hipGetLastError());
     if (shard) {
         if (!c->comm_ready) FAIL(c, VBMF_ERR_COMM, "nranks > 1 but vbmf_comm_init was not called");
@@ -578,6 +611,23 @@ static int fold_Q_slabs(vbmf_ctx* c) {
 
 static int do_update_B(vbmf_ctx* c) {
     TRY(ensure_gram_A(c));
+    // un-split pass at H <= 64: B, its tiles and the Gram partials come out of the pass's register epilogue
+    const bool epi = fused_gram(c) && c->d2.nsplit == 1 && (c->d2.XT / nxw_of(c->NH) + 3) / 4 <= c->gslab_cap;
+    if (epi) {
+        int nslab = 0;
+        if (fused_ctrl(c)) {
+            TRY(launch_stream(c, 1, CTRL_COV_B | CTRL_EIG_BOLD, true, &nslab));
+        } else {
+            TRY(launch_ctrl_cov(c, 1));
+            TRY(launch_stream(c, 1, 0, true, &nslab));
+        }
+        TRY(launch_pair_reduce(c, 1, nslab));
+        c->bcur ^= 1;
+        c->gB_valid = true;
+        c->P_valid = false;
+        c->kb_identity = true;
+        return VBMF_OK;
+    }
     if (fused_ctrl(c)) {
         TRY(launch_stream(c, 1, CTRL_COV_B | CTRL_EIG_BOLD));
     } else if (side_overlap(c)) {
@@ -774,7 +824,13 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
     ALLOC(c->SA32, (size_t)c->Hp * c->Hp * 4);
     ALLOC(c->SB32, (size_t)c->Hp * c->Hp * 4);
     const int nchunk = std::max(cdiv(c->d1.XT, c->tiles_per_chunk), cdiv(c->d2.XT, c->tiles_per_chunk));
-    ALLOC(c->gslab, std::max((size_t)nchunk * 2 * c->Hp * c->Hp * 4, (size_t)256 * 2 * 3 * 1024 * 4));
+    // Gram partial slabs: one per chunk (generic path), per post_gram workgroup (<= 256), or per pass-2 workgroup when the
+    // pass carries the register epilogue (capped at 1024 slabs = 24 MB; longer shards use the separate post kernel)
+    {
+        const int epi_blocks = (c->NH <= 2) ? std::min(1024, (c->d2.XT / nxw_of(c->NH) + 3) / 4) : 0;
+        c->gslab_cap = std::max(256, epi_blocks);
+        ALLOC(c->gslab, std::max((size_t)nchunk * 2 * c->Hp * c->Hp * 4, (size_t)c->gslab_cap * 2 * 3 * 1024 * 4));
+    }
     ALLOC(c->st, (size_t)c->lay.total() * 8);
     ALLOC(c->gtmp, (size_t)2 * c->Hp * c->Hp * 8);
     ALLOC(c->ypart, (size_t)16384 * 8);
@@ -1376,7 +1432,12 @@ int vbmf_pass_bytes(vbmf_ctx* c, int pass, double* bytes) {
     const double ybytes = (c->mode == MODE_F32) ? 4.0 : 2.0;
     const double LM = (double)c->L * (double)c->M;
     if (pass == 1) *bytes = LM * ybytes + (double)c->L * c->H * 4.0 + (double)c->M * c->H * 4.0;
-    else *bytes = LM * ybytes + (double)c->M * c->H * 4.0 + (double)c->L * c->H * 4.0;
+    else {
+        // with the register epilogue (un-split pass, H <= 64) the launch writes B and re-reads B_old instead of writing
+        // the product: SURVEY 8d's "B written and B_old re-read in pass 2"
+        const bool epi = c->NH <= 2 && c->d2.nsplit == 1 && (c->d2.XT / nxw_of(c->NH) + 3) / 4 <= c->gslab_cap;
+        *bytes = LM * ybytes + (double)c->M * c->H * 4.0 + (double)c->L * c->H * 4.0 * (epi ? 2.0 : 1.0);
+    }
     return VBMF_OK;
 }
 
