@@ -19,8 +19,8 @@ for c in ("fetch_size","write_size"):
     if not f: print("no counter file for",c); continue
     agg=collections.defaultdict(list)
     for r in csv.DictReader(open(f[0])):
-        agg[r["Kernel_Name"][:48]].append(float(r["Counter_Value"]))
+        agg[r["Kernel_Name"][:64]].append(float(r["Counter_Value"]))
     print("==",c,"(KB per launch as reported; FETCH_SIZE reads 1/2 of wide streaming loads on gfx950)")
     for k,v in sorted(agg.items(), key=lambda kv:-sum(kv[1]))[:8]:
-        print(f"  {k:48s} n={len(v):4d} avg={sum(v)/len(v):14.1f}")
+        print(f"  {k:64s} n={len(v):4d} avg={sum(v)/len(v):14.1f}")
 PY
