@@ -115,6 +115,56 @@ __global__ __launch_bounds__(256) void post_kernel(const float* __restrict__ In,
     }
 }
 
+// ---- the inverse of write_factor_tiles: the fp32 factor values a tile's operand fragments encode (hi + lo) ------
+template <int MODE, int NH>
+__device__ __forceinline__ void read_factor_tiles(const uint4* __restrict__ Ft, f32x16& v, int xt, int nh, int lane) {
+    constexpr int NPART = ModeTraits<MODE>::NPART;
+    if constexpr (MODE == MODE_F32) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const uint4 o = Ft[((long long)(4 * xt + g) * NH + nh) * 64 + lane];
+            v[4 * g + 0] = bitsf(o.x); v[4 * g + 1] = bitsf(o.y); v[4 * g + 2] = bitsf(o.z); v[4 * g + 3] = bitsf(o.w);
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const long long base = (long long)(2 * xt + s) * NPART;
+            const uint4 h = Ft[((base + 0) * NH + nh) * 64 + lane];
+            const unsigned hw[4] = {h.x, h.y, h.z, h.w};
+            unsigned lw[4] = {0u, 0u, 0u, 0u};
+            if constexpr (NPART == 2) {
+                const uint4 l = Ft[((base + 1) * NH + nh) * 64 + lane];
+                lw[0] = l.x; lw[1] = l.y; lw[2] = l.z; lw[3] = l.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const unsigned short hb = (unsigned short)(hw[e >> 1] >> (16 * (e & 1)));
+                float f = bf2f(hb);
+                if constexpr (NPART == 2) f += bf2f((unsigned short)(lw[e >> 1] >> (16 * (e & 1))));
+                v[8 * s + e] = f;
+            }
+        }
+    }
+}
+
+// fp32 row-major factor from its operand tiles (the lazy counterpart of the register epilogue's fp32 store)
+template <int MODE, int NH>
+__global__ __launch_bounds__(256) void untile_factor_kernel(const uint4* __restrict__ Ft, float* __restrict__ Fac, int XT) {
+    constexpr int Hp = NH * 32;
+    const int lane = threadIdx.x & 63;
+    const int xt = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (xt >= XT) return;
+    const int c = lane & 31, half = lane >> 5;
+    const long long x0 = (long long)xt * 32;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        f32x16 v;
+        read_factor_tiles<MODE, NH>(Ft, v, xt, h, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Fac[(x0 + rho(r, half)) * Hp + h * 32 + c] = v[r];
+    }
+}
+
 // ---- one 32-row tile of "post + Gram" from a product tile that is still in accumulator registers --------------
 // q[hin][r] on lane (half, c) holds (Y A)[x0 + c][hin*32 + rho(r, half)] -- the streaming kernel's accumulator as it
 // stands.  An exact-f32 MFMA of k = 2 takes its two k values from the two lane halves, and the contraction may run in
@@ -126,7 +176,7 @@ __device__ __forceinline__ void post_gram_tile_regs(const f32x16 (&q)[NH], const
                                                     float* __restrict__ Fac, const float* __restrict__ Prev,
                                                     uint4* __restrict__ Ft, int lane,
                                                     f32x16 (&G)[NH * (NH + 1) / 2], f32x16 (&D)[NH * (NH + 1) / 2],
-                                                    const f32x16 (&pv)[NH]) {
+                                                    const f32x16 (&pv)[NH], int store_fac) {
     constexpr int Hp = NH * 32;
     const int c = lane & 31, half = lane >> 5;
     const long long x0 = (long long)xt * 32;
@@ -148,8 +198,10 @@ __device__ __forceinline__ void post_gram_tile_regs(const f32x16 (&q)[NH], const
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
         write_factor_tiles<MODE, NH>(Ft, acc[h], xt, h, lane);
+        if (store_fac) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) Fac[(x0 + rho(r, half)) * Hp + h * 32 + c] = acc[h][r];
+            for (int r = 0; r < 16; ++r) Fac[(x0 + rho(r, half)) * Hp + h * 32 + c] = acc[h][r];
+        }
     }
     int p = 0;
 #pragma unroll

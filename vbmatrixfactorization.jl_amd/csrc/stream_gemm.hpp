@@ -51,6 +51,7 @@ struct EpiArgs {
     const float* S; float* Fac; const float* Prev; uint4* Ft; float* slabs;
     const int* sready; int expect;           // expect < 0: the table was complete before the launch
     int* err;
+    int store_fac;                           // 0 inside vbmf_run: the fp32 factor is rebuilt from the tiles once, at the end
 };
 
 // FDBG (tuning harness only): 1 = the factor ring re-reads one L1-hot k-step, 2 = no factor refills at all
@@ -251,17 +252,16 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const uint4* __restric
         if (active) {
             // the previous factor's rows of all this wave's tiles first (they are only needed for the delta-Gram at the
             // end of each tile: one round of memory latency instead of one per tile)
+            // read from the factor's OPERAND TILES (they encode exactly the fp32 factor): 1 KiB wave loads
             f32x16 pv[NXW_][NH];
 #pragma unroll
             for (int i = 0; i < NXW_; ++i)
 #pragma unroll
-                for (int h = 0; h < NH; ++h)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        pv[i][h][r] = epi.Prev[((long long)(xg * NXW_ + i) * 32 + rho(r, half)) * Hp + h * 32 + c];
+                for (int h = 0; h < NH; ++h) read_factor_tiles<MODE, NH>(epi.Ft, pv[i][h], xg * NXW_ + i, h, lane);
 #pragma unroll
             for (int i = 0; i < NXW_; ++i)
-                post_gram_tile_regs<MODE, NH>(acc[i], sperm, xg * NXW_ + i, epi.Fac, epi.Prev, epi.Ft, lane, G, D, pv[i]);
+                post_gram_tile_regs<MODE, NH>(acc[i], sperm, xg * NXW_ + i, epi.Fac, epi.Prev, epi.Ft, lane, G, D, pv[i],
+                                              epi.store_fac);
         }
         // fold the four waves' partials (fixed order => deterministic), then one coalesced slab store per workgroup
         for (int wv = 0; wv < 4; ++wv) {

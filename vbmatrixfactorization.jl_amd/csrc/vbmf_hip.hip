@@ -89,6 +89,7 @@ struct vbmf_ctx {
     bool use_side = false, side_pending = false;
     bool in_run = false;              // inside vbmf_run: the control chain rides in workgroups 0-1 of the pass launches
     int gslab_cap = 256;
+    bool B32_stale = false;           // the register epilogue skipped the fp32 store of B (inside vbmf_run): tiles are current
     int sready_seq = 0;               // sequence number of the Sigma-table release flag (register epilogue)
     int64_t ends_enqueued = 0;        // sweeps whose closing control step has been enqueued in this run (trace row)
     bool tail_pending = false;        // eig + ctrl_end of the last enqueued sweep not issued yet
@@ -285,6 +286,8 @@ static int launch_stream(vbmf_ctx* c, int pass, int ctrl_mode = 0, bool epi = fa
         c->sready_seq = (c->sready_seq + 1) & 0x3fffffff;
         ea.S = c->SB32; ea.Fac = c->B32[c->bcur ^ 1]; ea.Prev = c->B32[c->bcur]; ea.Ft = c->FB; ea.slabs = c->gslab;
         ea.sready = c->ints + I_SREADY; ea.expect = ctrl_mode ? c->sready_seq : -1; ea.err = c->ints + I_ERR;
+        ea.store_fac = c->in_run ? 0 : 1;
+        if (c->in_run) c->B32_stale = true;
         if (ctrl_mode) { ca.sready = c->ints + I_SREADY; ca.sready_val = c->sready_seq; }
         if (epi_slabs) *epi_slabs = bps;
     }
@@ -1162,6 +1165,7 @@ int vbmf_set_state(vbmf_ctx* c, const double* AHat, int64_t ldA, const double* B
     HIPCHK(c, hipMemsetAsync(c->ints, 0, 16 * sizeof(int), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->gA_valid = c->gB_valid = c->P_valid = c->kb_identity = false;
+    c->B32_stale = false;
     c->haveState = true;
     return VBMF_OK;
 }
@@ -1316,6 +1320,15 @@ int vbmf_run(vbmf_ctx* c, int64_t niter, double eps, int est_covs, int est_var, 
     if (rc == VBMF_OK) {
         const int done = c->ints_host[I_ITERS];
         c->bcur = bstart ^ (done & 1);                    // sweeps after `stop` were no-ops on the device
+        if (c->B32_stale) {                               // the fp32 factor from the tiles the last executed sweep wrote
+            const int grid = (c->d2.XT + 3) / 4;
+            DISPATCH_MODE(c->mode, {
+                if (c->NH == 1) hipLaunchKernelGGL((untile_factor_kernel<MODEc, 1>), dim3(grid), dim3(256), 0, c->stream, c->FB, c->B32[c->bcur], c->d2.XT);
+                else hipLaunchKernelGGL((untile_factor_kernel<MODEc, 2>), dim3(grid), dim3(256), 0, c->stream, c->FB, c->B32[c->bcur], c->d2.XT);
+            });
+            if (hipStreamSynchronize(c->stream) != hipSuccess) { c->err = "factor rebuild failed"; rc = VBMF_ERR_HIP; }
+            c->B32_stale = false;
+        }
         if (iters_done) *iters_done = done;
         if (d_last && done > 0) *d_last = c->scal_host[S_D];
         if (trace && done > 0) {
