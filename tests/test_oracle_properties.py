@@ -1,0 +1,150 @@
+"""Properties of the CPU oracle that hold independently of any recorded number (CPU-only): they guard the parts of the
+restatement the reference's fixtures do not pin (SURVEY.md section 8c "parity unpinned") against plain mistakes --
+the fused/faithful orderings agree, the build-defined ELBO ascends, the literal loops of the reference's source agree
+with the vectorised restatements, and the diagonal sparse branch is the diagonal of the pinned full-covariance branch."""
+import copy
+
+import numpy as np
+import pytest
+
+from oracle import vbmf_oracle as O
+
+
+def _problem(L, M, H, seed, **kw):
+    rng = np.random.default_rng(seed)
+    Y, A, B = O.toy_matrix(L, M, H, 0.05, rng)
+    Y = (B * np.linspace(1.0, 2.5, H)) @ A.T + 0.05 * rng.standard_normal((L, M))
+    return Y, O.vbmf_init(Y, H, ca=0.1, cb=0.1, sigma2=0.1, rng=np.random.default_rng(seed + 1), **kw)
+
+
+def test_fused_and_faithful_orderings_agree():
+    """updateSigma2! literally (Y.^2, 2Y', the M x M product: src/vbmf.jl:153-157) vs the fused form every GPU kernel
+    and the CPU baseline's `fused_value` use."""
+    Y, p = _problem(60, 45, 4, 1)
+    q = O.copy_params(p)
+    for f in ("AHat", "BHat", "SigmaA", "SigmaB", "CA", "CB", "invCA", "invCB"):
+        setattr(q, f, getattr(p, f).copy())
+    O.vbmf_(Y, p, 12, eps=0.0, est_covs=True, est_var=True, fused=False)
+    O.vbmf_(Y, q, 12, eps=0.0, est_covs=True, est_var=True, fused=True)
+    for f in ("AHat", "BHat", "SigmaA", "SigmaB", "CA", "CB"):
+        assert np.allclose(getattr(p, f), getattr(q, f), rtol=1e-8, atol=1e-12), f
+    assert p.sigma2 == pytest.approx(q.sigma2, rel=1e-9)
+
+
+def test_elbo_ascends_with_frozen_hyperparameters():
+    """Coordinate ascent on q(A), q(B) with C_A, C_B, sigma2 fixed cannot lower the bound."""
+    Y, p = _problem(80, 50, 3, 2)
+    tr = []
+    O.vbmf_(Y, p, 15, eps=0.0, est_covs=False, est_var=False, trace=tr)
+    e = np.array([t[2] for t in tr])
+    assert np.all(np.isfinite(e)) and np.all(np.diff(e) >= -1e-9 * np.abs(e[:-1])), e
+
+
+def test_delta_is_the_spectral_norm_ratio():
+    """delta = norm(old - new) / norm(old) with Julia 0.5's norm(::Matrix) = largest singular value (src/util.jl:27-29)."""
+    rng = np.random.default_rng(3)
+    a, b = rng.standard_normal((30, 4)), rng.standard_normal((30, 4))
+    want = np.linalg.svd(b - a, compute_uv=False)[0] / np.linalg.svd(b, compute_uv=False)[0]
+    assert O.delta(a, b) == pytest.approx(want, rel=1e-12)
+    fro = np.linalg.norm(b - a) / np.linalg.norm(b)
+    assert abs(O.delta(a, b) - fro) > 1e-3                     # and it is NOT the Frobenius ratio
+    with np.errstate(all="ignore"):
+        assert np.isnan(O.delta(np.zeros((3, 2)), np.zeros((3, 2))))   # 0/0 -> NaN -> the loop exits (App. A Q6)
+
+
+def test_mask_and_termination():
+    Y, p = _problem(40, 30, 4, 4, H1=2, labels=[1, 5, 9])
+    assert np.all(p.AHat[[1, 5, 9], 2:] == 0.0)               # masked at init (src/vbmf.jl:61)
+    _, n, d = O.vbmf_(Y, p, 200, eps=1e-3, est_covs=True, est_var=True)
+    assert np.all(p.AHat[[1, 5, 9], 2:] == 0.0) and np.all(p.AHat[[0, 2], 2:] != 0.0)
+    assert 1 <= n < 200 and d <= 1e-3                          # while i <= niter && d > eps (:193)
+    q = copy.deepcopy(p)
+    _, n0, d0 = O.vbmf_(Y, q, 0, eps=1e-3)
+    assert n0 == 0 and d0 == 1e-3 + 1.0                        # d = eps + 1 before the loop (:189)
+
+
+def test_sparse_diagonal_branch_is_the_diagonal_of_the_pinned_full_branch():
+    """With the consistent layout (reference_compat=False) and CA a per-column constant, the diagonal branch
+    (src/vbmf_sparse.jl:214-239) equals the full-covariance branch (:178-202, pinned by the fixture) whenever the full
+    posterior precision is itself diagonal, i.e. B'B + L SigmaB diagonal -- and QS2 is visible as the one difference."""
+    rng = np.random.default_rng(5)
+    L, M, H = 12, 7, 3
+    Q, _ = np.linalg.qr(rng.standard_normal((L, H)))
+    B = Q * np.array([1.0, 2.0, 0.5])                           # orthogonal columns: B'B diagonal
+    Y = rng.standard_normal((L, M))
+    base = O.vbmf_sparse_init(Y, H, ca=0.7, cb=1.0, sigma=1.0, rng=rng, full_cov=True)
+    base.BHat = B
+    base.SigmaB = np.diag([0.01, 0.02, 0.03])
+    full, diag = copy.deepcopy(base), copy.deepcopy(base)
+    O.sparse_updateA(Y, full, full_cov=True)
+    O.sparse_updateA(Y, diag, full_cov=False, reference_compat=False)
+    # sigmaHat = 1 makes QS2 (sigmaHat not multiplying L*SigmaB in the diagonal branch) vanish
+    assert np.allclose(full.ATVecHat, diag.ATVecHat, rtol=1e-10) and np.allclose(full.SigmaA, diag.SigmaA, rtol=1e-10)
+    base.sigmaHat = 3.0
+    full, diag = copy.deepcopy(base), copy.deepcopy(base)
+    O.sparse_updateA(Y, full, full_cov=True)
+    O.sparse_updateA(Y, diag, full_cov=False, reference_compat=False)
+    assert not np.allclose(full.diagSigmaATVec, diag.diagSigmaATVec, rtol=1e-3)       # QS2
+    v_full = 3.0 * (np.sum(B * B, axis=0) + L * np.diag(base.SigmaB))
+    v_diag = 3.0 * np.sum(B * B, axis=0) + L * np.diag(base.SigmaB)
+    assert np.allclose(1.0 / (np.tile(v_full, M) + base.CA), full.diagSigmaATVec)
+    assert np.allclose(1.0 / (np.tile(v_diag, M) + base.CA), diag.diagSigmaATVec)
+
+
+def test_repeat_layout_quirk():
+    """repeat(v, inner = M-1) after the first H entries (src/vbmf_sparse.jl:221, App. A QS1)."""
+    v = np.array([10.0, 20.0, 30.0])
+    got = O.spread_v(v, 4, reference_compat=True)
+    assert got.tolist() == [10, 20, 30, 10, 10, 10, 20, 20, 20, 30, 30, 30]
+    assert O.spread_v(v, 4, reference_compat=False).tolist() == [10, 20, 30] * 4
+
+
+def test_heteroscedastic_sigma_matches_the_literal_row_loop():
+    """updateSigma!, diag_var = true (src/vbmf_sparse.jl:309-315) written row by row as in the source."""
+    rng = np.random.default_rng(6)
+    L, M, H = 15, 9, 3
+    Y = rng.standard_normal((L, M))
+    p = O.vbmf_sparse_init(Y, H, rng=rng, full_cov=False)
+    p.SigmaA = np.diag(rng.uniform(0.1, 1.0, H)); p.SigmaB = np.diag(rng.uniform(0.1, 1.0, H))
+    q = copy.deepcopy(p)
+    O.sparse_updateSigma(Y, p, diag_var=True)
+    for l in range(L):
+        z = (q.zeta0 + 0.5 * np.sum(Y[l] ** 2) - np.sum(Y[l] * (q.AHat @ q.BHat[l]))
+             + 0.5 * np.sum((q.AHat.T @ q.AHat + q.SigmaA) * (np.outer(q.BHat[l], q.BHat[l]) + q.SigmaB)))
+        assert p.zetaVec[l] == pytest.approx(z, rel=1e-12)
+        assert p.sigmaVecHat[l] == pytest.approx(q.etaVec[l] / z, rel=1e-12)
+
+
+def test_lower_bound_entropy_term_equals_the_kron_determinant():
+    """H(B) = normalEntropy(kron(SigmaB, I_L)) (src/vbmf_sparse.jl:463) restated as L * logdet(SigmaB) (App. A QS5)."""
+    rng = np.random.default_rng(7)
+    L, H = 4, 3
+    X = rng.standard_normal((H, H)); S = X @ X.T + np.eye(H)
+    big = np.kron(S, np.eye(L))
+    sign, ld = np.linalg.slogdet(big)
+    want = 0.5 * (L * H) * (1.0 + O.LN2PI) + 0.5 * ld
+    got = O.normalEntropy_matrix_logdet(L * H, L * np.linalg.slogdet(S)[1], clamp=True)
+    assert got == pytest.approx(want, rel=1e-12)
+
+
+def test_scaleY_and_preprocess():
+    rng = np.random.default_rng(8)
+    Y = rng.standard_normal((9, 40)) * 3.0 + 5.0
+    Y[2] = 4.0                                                  # constant row: dropped by preprocess
+    s = O.scaleY(Y)
+    keep = np.arange(9) != 2
+    assert np.allclose(s[keep].mean(axis=1), 0.0, atol=1e-12) and np.allclose(s[keep].var(axis=1, ddof=1), 1.0)
+    assert np.all(s[2] == 0.0)
+    out, rows = O.preprocess(Y, 0.5, return_rows=True)
+    assert rows.tolist() == [0, 1, 3, 4, 5, 6, 7, 8] and np.allclose(out, 0.5 * s[keep])
+
+
+def test_vbls_keeps_the_basis_fixed():
+    Y, p = _problem(50, 35, 3, 9)
+    O.vbmf_(Y, p, 10, eps=0.0, est_covs=True, est_var=True)
+    Y2 = Y[:, :20].copy()
+    q = O.copy_vbmf_params(Y2, p, rng=np.random.default_rng(1))
+    assert q.M == 20 and np.array_equal(q.BHat, p.BHat) and q.sigma2 == p.sigma2
+    B0 = q.BHat.copy()
+    A = O.vbls_(Y2, q, 8)
+    assert A is q.AHat and np.array_equal(q.BHat, B0) and np.isfinite(q.sigma2)
