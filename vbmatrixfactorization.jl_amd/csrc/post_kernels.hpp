@@ -63,8 +63,11 @@ __device__ __forceinline__ void write_factor_tiles(uint4* __restrict__ Ft, f32x1
     }
 }
 
-// One wave per 32-row tile of the factor.  In: [nslab][Hp][ldIn] fp32 (x fastest), S: [Hp][Hp] fp32
-// row-major, Fac: [XT*32][Hp] fp32 row-major.
+// One wave per NXT consecutive 32-row tiles of the factor (NXT = 1 up to H = 64; from H = 128 on several tiles share
+// every fetch of the H x H table, which no longer fits a wave's registers: 16 accumulator tiles per wave).
+// In: [nslab][Hp][ldIn] fp32 (x fastest), S: [Hp][Hp] fp32 row-major, Fac: [XT*32][Hp] fp32 row-major.
+template <int NH> struct PostCfg { static constexpr int NXT = NH >= 8 ? 2 : (NH == 4 ? 4 : 1); };
+
 template <int MODE, int NH>
 __global__ __launch_bounds__(256) void post_kernel(const float* __restrict__ In, long long ldIn, int nslab,
                                                    long long slabStride, const float* __restrict__ S,
@@ -72,46 +75,64 @@ __global__ __launch_bounds__(256) void post_kernel(const float* __restrict__ In,
                                                    const unsigned char* __restrict__ mask, int hmask_start, int XT,
                                                    const int* __restrict__ stop) {
     constexpr int Hp = NH * 32;
+    constexpr int NXT = PostCfg<NH>::NXT;
     if (stop && *stop) return;
     const int lane = threadIdx.x & 63;
-    const int xt = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (xt >= XT) return;
+    const int xt0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * NXT;
+    if (xt0 >= XT) return;
     const int c = lane & 31, half = lane >> 5;
-    const long long x0 = (long long)xt * 32;
 
-    f32x16 acc[NH];
+    f32x16 acc[NXT][NH];
 #pragma unroll
-    for (int h = 0; h < NH; ++h)
+    for (int i = 0; i < NXT; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[h][r] = 0.f;
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][h][r] = 0.f;
 
     for (int hin = 0; hin < NH; ++hin) {
+        // (unrolling all 16 steps to put more of the 4-byte product loads in flight spills and is slower: 419 vs 382 us)
 #pragma unroll 4
         for (int t = 0; t < 16; ++t) {
             const int hk = hin * 32 + 2 * t + half;               // contraction index of this lane-half
-            const float* ip = In + (long long)hk * ldIn + x0 + c;
-            float a = 0.f;
-            for (int s = 0; s < nslab; ++s) a += ip[(long long)s * slabStride];
+            float a[NXT];
+#pragma unroll
+            for (int i = 0; i < NXT; ++i) {
+                // tiles past XT (ragged last wave) read tile XT-1 again and are dropped at the store
+                const int xt = xt0 + i < XT ? xt0 + i : XT - 1;
+                const float* ip = In + (long long)hk * ldIn + (long long)xt * 32 + c;
+                float v = 0.f;
+                for (int s = 0; s < nslab; ++s) v += ip[(long long)s * slabStride];
+                a[i] = v;
+            }
 #pragma unroll
             for (int h = 0; h < NH; ++h) {
                 const float b = S[(long long)hk * Hp + h * 32 + c];
-                acc[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[h], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < NXT; ++i)
+                    acc[i][h] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b, acc[i][h], 0, 0, 0);
             }
         }
     }
 
     // accumulator layout: lane (c = h' in tile, half), register r -> row x0 + rho(r, half)
 #pragma unroll
-    for (int h = 0; h < NH; ++h) {
-        const int hcol = h * 32 + c;
-        if (mask != nullptr && hcol >= hmask_start) {
+    for (int i = 0; i < NXT; ++i) {
+        const int xt = xt0 + i;
+        if (xt >= XT) break;
+        const long long x0 = (long long)xt * 32;
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (mask[x0 + rho(r, half)]) acc[h][r] = 0.f;
+        for (int h = 0; h < NH; ++h) {
+            const int hcol = h * 32 + c;
+            if (mask != nullptr && hcol >= hmask_start) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (mask[x0 + rho(r, half)]) acc[i][h][r] = 0.f;
+            }
+            write_factor_tiles<MODE, NH>(Ft, acc[i][h], xt, h, lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Fac[(x0 + rho(r, half)) * Hp + hcol] = acc[i][h][r];
         }
-        write_factor_tiles<MODE, NH>(Ft, acc[h], xt, h, lane);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) Fac[(x0 + rho(r, half)) * Hp + hcol] = acc[h][r];
     }
 }
 

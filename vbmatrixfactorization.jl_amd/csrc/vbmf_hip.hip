@@ -337,7 +337,8 @@ static int launch_post(vbmf_ctx* c, int which, const float* In, int nslab) {
     uint4* Ft = which == 0 ? c->FA : c->FB;
     const unsigned char* mk = (which == 0 && c->has_mask) ? c->mask : nullptr;
     const int hstart = (int)(c->H - c->H1);
-    const int grid = (d.XT + 3) / 4;
+    const int nxt = c->NH >= 8 ? 2 : (c->NH == 4 ? 4 : 1);       // = PostCfg<NH>::NXT
+    const int grid = (cdiv(d.XT, nxt) + 3) / 4;
     DISPATCH_MODE(c->mode, DISPATCH_NH(c->NH, {
         hipLaunchKernelGGL((post_kernel<MODEc, NHc>), dim3(grid), dim3(256), 0, c->stream, In, ld, nslab, slabStride, S,
                            Fac, Ft, mk, hstart, d.XT, c->ints + I_STOP);
