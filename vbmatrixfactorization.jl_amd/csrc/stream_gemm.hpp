@@ -47,6 +47,11 @@ constexpr int Y_AUX = 2;
 // / sigma2, its operand tiles, the fp32 factor and the Gram / delta-Gram partials are produced right here
 // (post_kernels.hpp, post_gram_tile_regs), which removes the L x H round trip through HBM and one launch per sweep.
 // SigmaB is computed by control workgroup 0 of this very launch: `sready` is its release flag.
+// (The flag may only be released by a workgroup of THIS launch -- those are dispatched first.  A stand-alone kernel on
+// another stream can be starved by the pass occupying every CU while its workgroups wait in their epilogues: tried for
+// H >= 128 with SigmaB on the side stream, it deadlocked until the bounded spin gave up.  A product-only epilogue for
+// H >= 128 (table streamed from L2, 2048 exact-f32 MFMAs per wave) was also measured: no faster than the separate
+// post kernel at 1M x 128, so H >= 128 keeps the product in HBM.)
 struct EpiArgs {
     const float* S; float* Fac; const float* Prev; uint4* Ft; float* slabs;
     const int* sready; int expect;           // expect < 0: the table was complete before the launch
