@@ -11,7 +11,8 @@
 module VBMatrixFactorizationHIP
 
 export vbmf_parameters, vbmf_init, vbmf, vbmf!, updateA!, updateB!, updateCA!, updateCB!, updateSigma2!, updateYHat!,
-       vbls!, copy_vbmf_params, preprocess_device, vbmf_on!
+       vbls!, copy_vbmf_params, preprocess_device, vbmf_on!,
+       vbmf_sparse_parameters, vbmf_sparse_init, vbmf_sparse!, lowerBound
 
 const libvbmf = get(ENV, "VBMF_HIP_LIB", joinpath(@__DIR__, "..", "libvbmf_hip.so"))
 
@@ -230,6 +231,115 @@ function vbmf_on!(c::Ctx, params::vbmf_parameters, niter::Int; eps::Float64 = 1e
         c.h, niter, eps, est_covs, est_var, iters, d, C_NULL))
     pull!(c, params)
     return params
+end
+
+# ---- the ARD-sparse variant, src/vbmf_sparse.jl (full_cov = false; diag_var = false | true) ---------------
+# Same field names as the reference's vbmf_sparse_parameters (src/vbmf_sparse.jl:47-90); the dense MH x MH
+# SigmaATVec / invSigmaATVec of the full_cov branch are not carried (they cannot exist at scale, :120,122).
+mutable struct vbmf_sparse_parameters
+    L::Int; M::Int; H::Int; MH::Int; H1::Int
+    labels::Array{Int64,1}
+    AHat::Array{Float64,2}; ATVecHat::Array{Float64,1}; diagSigmaATVec::Array{Float64,1}; SigmaA::Array{Float64,2}
+    BHat::Array{Float64,2}; SigmaB::Array{Float64,2}
+    CA::Array{Float64,1}; alpha0::Float64; beta0::Float64; alpha::Float64; beta::Array{Float64,1}
+    CB::Array{Float64,1}; gamma0::Float64; delta0::Float64; gamma::Float64; delta::Array{Float64,1}
+    sigmaHat::Float64; eta0::Float64; zeta0::Float64; eta::Float64; zeta::Float64
+    sigmaVecHat::Array{Float64,1}; etaVec::Array{Float64,1}; zetaVec::Array{Float64,1}
+    YHat::Array{Float64,2}; trYTY::Float64
+    vbmf_sparse_parameters() = new()
+end
+
+struct SparseHyper
+    alpha0::Float64; beta0::Float64; gamma0::Float64; delta0::Float64; eta0::Float64; zeta0::Float64
+end
+
+"src/vbmf_sparse.jl:101-153"
+function vbmf_sparse_init(Y::Array{Float64,2}, H::Int; ca = 1.0, alpha0 = 1e-10, beta0 = 1e-10, cb = 1.0, gamma0 = 1e-10,
+                          delta0 = 1e-10, sigma = 1.0, eta0 = 1e-10, zeta0 = 1e-10, H1::Int = 0,
+                          labels::Array{Int64,1} = Array{Int64,1}())
+    p = vbmf_sparse_parameters(); L, M = size(Y)
+    p.L, p.M, p.H, p.MH, p.H1, p.labels = L, M, H, M * H, H1, labels
+    p.AHat = randn(M, H); p.AHat[labels, end-H1+1:end] .= 0.0
+    p.ATVecHat = reshape(permutedims(p.AHat), M * H); p.diagSigmaATVec = ones(M * H); p.SigmaA = zeros(H, H)
+    p.BHat = randn(L, H); p.SigmaB = zeros(H, H)
+    p.CA = ca * ones(M * H); p.alpha0, p.beta0, p.alpha, p.beta = alpha0, beta0, alpha0 + 0.5, beta0 * ones(M * H)
+    p.CB = cb * ones(H); p.gamma0, p.delta0, p.gamma, p.delta = gamma0, delta0, gamma0 + L / 2, delta0 * ones(H)
+    p.sigmaHat, p.eta0, p.zeta0, p.eta, p.zeta = sigma, eta0, zeta0, eta0 + L * M / 2, zeta0
+    p.sigmaVecHat, p.etaVec, p.zetaVec = sigma * ones(L), (eta0 + M / 2) * ones(L), zeta0 * ones(L)
+    p.YHat = L * M <= (1 << 24) ? p.BHat * p.AHat' : Array{Float64}(undef, 0, 0)
+    p.trYTY = sum(abs2, Y)
+    return p
+end
+
+const _scache = Dict{UInt,Ctx}()
+function sparse_ctx_for(Y::Array{Float64,2}, H::Int, diag_var::Bool)
+    key = hash((objectid(Y), size(Y), H, diag_var))
+    haskey(_scache, key) && return _scache[key]
+    L, M = size(Y)
+    ydt = get(ENV, "VBMF_HIP_Y", "bf16") == "f32" ? VBMF_Y_F32 : VBMF_Y_BF16
+    opts = Ref(VbmfOpts(Int32(sizeof(VbmfOpts)), 0, ydt, 0, diag_var ? 2 : 1, 0xffffffff, 1, 0, 0, 0, 0, 0))   # variant
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    chk(Ptr{Cvoid}(C_NULL), ccall((:vbmf_create, libvbmf), Cint, (Ref{Ptr{Cvoid}}, Int64, Int64, Int64, Ref{VbmfOpts}), h, L, M, H, opts))
+    chk(h[], ccall((:vbmf_set_Y, libvbmf), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64), h[], Y, L))
+    c = Ctx(h[], Y); finalizer(x -> ccall((:vbmf_destroy, libvbmf), Cint, (Ptr{Cvoid},), x.h), c)
+    _scache[key] = c
+    return c
+end
+
+function spush!(c::Ctx, p::vbmf_sparse_parameters, diag_var::Bool)
+    hy = Ref(SparseHyper(p.alpha0, p.beta0, p.gamma0, p.delta0, p.eta0, p.zeta0)); lab0 = p.labels .- 1
+    chk(c.h, ccall((:vbmf_sparse_set_state, libvbmf), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64},
+         Ptr{Float64}, Float64, Float64, Ref{SparseHyper}, Ptr{Int64}, Int64, Int64),
+        c.h, p.ATVecHat, p.diagSigmaATVec, p.CA, p.beta, p.BHat, p.L, p.SigmaB, p.CB, p.delta, p.sigmaHat, p.zeta, hy,
+        lab0, length(lab0), p.H1))
+    diag_var && chk(c.h, ccall((:vbmf_sparse_set_noise_rows, libvbmf), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Float64),
+                               c.h, p.sigmaVecHat, p.zetaVec, p.etaVec[1]))
+end
+
+function spull!(c::Ctx, p::vbmf_sparse_parameters, diag_var::Bool)
+    n = p.M * p.H
+    a = Array{Float64}(undef, n); ds = similar(a); ca = similar(a); be = similar(a); sa = Array{Float64}(undef, p.H)
+    B = Array{Float64}(undef, p.L, p.H); SB = Array{Float64}(undef, p.H, p.H); cb = Array{Float64}(undef, p.H); dl = similar(cb)
+    sh = Ref{Float64}(0.0); ze = Ref{Float64}(0.0)
+    chk(c.h, ccall((:vbmf_sparse_get_state, libvbmf), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Float64},
+         Ptr{Float64}, Ptr{Float64}, Ref{Float64}, Ref{Float64}),
+        c.h, a, ds, ca, be, sa, B, p.L, SB, cb, dl, sh, ze))
+    p.ATVecHat, p.diagSigmaATVec, p.CA, p.beta = a, ds, ca, be
+    p.AHat = permutedims(reshape(a, p.H, p.M)); p.SigmaA = [i == j ? sa[i] : 0.0 for i in 1:p.H, j in 1:p.H]
+    p.BHat, p.SigmaB, p.CB, p.delta = B, SB, cb, dl
+    if diag_var
+        s = Array{Float64}(undef, p.L); z = similar(s)
+        chk(c.h, ccall((:vbmf_sparse_get_noise_rows, libvbmf), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), c.h, s, z))
+        p.sigmaVecHat, p.zetaVec = s, z
+    else
+        p.sigmaHat, p.zeta = sh[], ze[]
+    end
+    return p
+end
+
+"vbmf_sparse! -- src/vbmf_sparse.jl:344-410 (returns d, like the reference)"
+function vbmf_sparse!(Y::Array{Float64,2}, params::vbmf_sparse_parameters, niter::Int; eps::Float64 = 1e-6, diag_var::Bool = false,
+                      full_cov::Bool = false, logdir = "", desc = "", verb = false, est_cb::Bool = true)
+    full_cov && error("only full_cov=false is built")
+    logdir == "" || error("trajectory logging lives in the Python host (data_manip.py)")
+    c = sparse_ctx_for(Y, params.H, diag_var); spush!(c, params, diag_var)
+    iters = Ref{Int64}(0); d = Ref{Float64}(0.0)
+    chk(c.h, ccall((:vbmf_sparse_run, libvbmf), Cint, (Ptr{Cvoid}, Int64, Float64, Cint, Ref{Int64}, Ref{Float64}, Ptr{Float64}),
+                   c.h, niter, eps, est_cb, iters, d, C_NULL))
+    spull!(c, params, diag_var)
+    params.L * params.M <= (1 << 24) && (params.YHat = params.BHat * params.AHat')            # :396
+    verb && print("Factorization finished after ", iters[], " iterations, eps = ", d[], "\n")
+    return d[]
+end
+
+"lowerBound -- src/vbmf_sparse.jl:435-471 (homoscedastic model)"
+function lowerBound(Y::Array{Float64,2}, params::vbmf_sparse_parameters)
+    c = sparse_ctx_for(Y, params.H, false); spush!(c, params, false)
+    lb = Ref{Float64}(0.0)
+    chk(c.h, ccall((:vbmf_sparse_lower_bound, libvbmf), Cint, (Ptr{Cvoid}, Cint, Ref{Float64}), c.h, 1, lb))
+    return lb[]
 end
 
 end # module
