@@ -148,3 +148,26 @@ def test_vbls_keeps_the_basis_fixed():
     B0 = q.BHat.copy()
     A = O.vbls_(Y2, q, 8)
     assert A is q.AHat and np.array_equal(q.BHat, B0) and np.isfinite(q.sigma2)
+
+
+@pytest.mark.parametrize("L,M,H", [(9, 6, 1), (9, 1, 3)])
+def test_diagonal_branch_equals_full_branch_when_the_precision_is_diagonal_by_shape(L, M, H):
+    """with H = 1 the H x H blocks of the full posterior precision are scalars, so the full
+    branch IS diagonal; with M = 1 the `repeat(v, inner = M-1)` tail is empty, so the QS1 layout coincides with the
+    consistent one.  In the full branch K = sigmaHat (B'B + L SigmaB); the diagonal branch's v differs by QS2 only, which
+    vanishes for sigmaHat = 1 -- and for H = 1, M >= 2 the reference layout still equals the consistent tiling."""
+    rng = np.random.default_rng(11)
+    Y = rng.standard_normal((L, M))
+    base = O.vbmf_sparse_init(Y, H, ca=0.6, cb=1.0, sigma=1.0, rng=rng, full_cov=True)
+    if H > 1:                                                    # M = 1: make B'B + L SigmaB diagonal so both branches agree
+        Q, _ = np.linalg.qr(rng.standard_normal((L, H)))
+        base.BHat = Q * np.array([1.0, 2.0, 0.5])
+    base.SigmaB = np.diag(rng.uniform(0.01, 0.05, H))
+    full, diag, diag_compat = copy.deepcopy(base), copy.deepcopy(base), copy.deepcopy(base)
+    O.sparse_updateA(Y, full, full_cov=True)
+    O.sparse_updateA(Y, diag, full_cov=False, reference_compat=False)
+    O.sparse_updateA(Y, diag_compat, full_cov=False, reference_compat=True)
+    for q in (diag, diag_compat):
+        assert np.allclose(q.ATVecHat, full.ATVecHat, rtol=1e-10, atol=1e-14)
+        assert np.allclose(q.diagSigmaATVec, full.diagSigmaATVec, rtol=1e-10)
+        assert np.allclose(q.SigmaA, full.SigmaA, rtol=1e-10)
