@@ -86,6 +86,7 @@ struct vbmf_ctx {
     // side stream beside the passes, ordered by events
     hipStream_t side = nullptr;
     hipEvent_t ev_main = nullptr, ev_side = nullptr;
+    hipEvent_t ev_chk[2] = {nullptr, nullptr};   // deferred look at the device's stop flag (vbmf_run)
     bool use_side = false, side_pending = false;
     bool in_run = false;              // inside vbmf_run: the control chain rides in workgroups 0-1 of the pass launches
     int gslab_cap = 256;
@@ -737,6 +738,7 @@ int vbmf_destroy(vbmf_ctx* c) {
     if (c->side) hipStreamDestroy(c->side);
     if (c->ev_main) hipEventDestroy(c->ev_main);
     if (c->ev_side) hipEventDestroy(c->ev_side);
+    for (auto& e : c->ev_chk) if (e) hipEventDestroy(e);
     delete c;
     return VBMF_OK;
 }
@@ -865,7 +867,9 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { c->err = "stream create failed"; return bail(VBMF_ERR_HIP); }
     if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming) != hipSuccess) { c->err = "side stream create failed"; return bail(VBMF_ERR_HIP); }
+        hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_chk[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_chk[1], hipEventDisableTiming) != hipSuccess) { c->err = "side stream create failed"; return bail(VBMF_ERR_HIP); }
     // large dynamic LDS (160 KiB per CU on gfx950) for the lambda_max kernel at 64 < H <= 128
     c->lds_limit = 160 * 1024 - 4096;
     {
@@ -1274,35 +1278,46 @@ int vbmf_run(vbmf_ctx* c, int64_t niter, double eps, int est_covs, int est_var, 
     c->run_flags = flags;
     c->run_eps = eps;
     c->run_trace = trace_dev;
+    // The host runs ahead of the device; every `check` sweeps it queues a copy of the device's stop/error flags and
+    // looks at the PREVIOUS copy (long complete), so the device never waits for the host.  Sweeps enqueued past the stop
+    // are no-ops on the device (every kernel begins with the stop test): at most 2*check of them.
     const int64_t check = 8;
     int64_t it = 0;
     bool stopped = false;
+    int slot = 0;
+    bool pending[2] = {false, false};
     while (rc == VBMF_OK && it < niter && !stopped) {
         rc = do_update_A(c);                 // carries lambda_max + ctrl_end of the previous sweep when fused
         if (rc == VBMF_OK) rc = do_update_B(c);
         ++it;
-        const bool checkpoint = (it % check == 0 || it == niter);
+        const bool last = (it == niter);
         if (rc == VBMF_OK) {
-            if (fused_ctrl(c) && !checkpoint) {
+            if (fused_ctrl(c) && !last) {
                 c->tail_pending = true;      // rides in the next sweep's pass-1 launch
             } else if (fused_ctrl(c)) {
                 rc = launch_eig(c, 1, 0);
                 if (rc == VBMF_OK) rc = launch_ctrl_end(c, flags | 32, eps, trace_dev);
                 ++c->ends_enqueued;
             } else {
-                // H > 128: beside the next sweep's Y'B pass (side stream); the checkpoint below joins first
+                // H > 128: beside the next sweep's Y'B pass (side stream)
                 if (side_overlap(c)) rc = side_fork(c);
                 if (rc == VBMF_OK) rc = launch_eig(c, 1, 1);
                 if (rc == VBMF_OK) rc = launch_ctrl_end(c, flags, eps, trace_dev);
                 if (rc == VBMF_OK && c->use_side) rc = side_end(c);
             }
         }
-        if (rc == VBMF_OK && checkpoint) rc = side_join(c);
-        if (rc == VBMF_OK && checkpoint) {
-            hipError_t e = hipMemcpyAsync(c->ints_host, c->ints, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-            if (e != hipSuccess) { c->err = std::string("run loop sync: ") + hipGetErrorString(e); rc = VBMF_ERR_HIP; break; }
-            if (c->ints_host[I_STOP] || c->ints_host[I_ERR]) stopped = true;
+        if (rc == VBMF_OK && !last && it % check == 0) {
+            if (pending[slot ^ 1]) {
+                if (hipEventSynchronize(c->ev_chk[slot ^ 1]) != hipSuccess) { c->err = "run loop sync failed"; rc = VBMF_ERR_HIP; break; }
+                const int* f = c->ints_host + 8 + 4 * (slot ^ 1);
+                if (f[I_STOP] || f[I_ERR]) stopped = true;
+                pending[slot ^ 1] = false;
+            }
+            hipError_t e = hipMemcpyAsync(c->ints_host + 8 + 4 * slot, c->ints, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipEventRecord(c->ev_chk[slot], c->stream);
+            if (e != hipSuccess) { c->err = std::string("run loop checkpoint: ") + hipGetErrorString(e); rc = VBMF_ERR_HIP; break; }
+            pending[slot] = true;
+            slot ^= 1;
         }
     }
     c->in_run = false;
