@@ -66,7 +66,7 @@ __device__ __forceinline__ void write_factor_tiles(uint4* __restrict__ Ft, f32x1
 // One wave per NXT consecutive 32-row tiles of the factor (NXT = 1 up to H = 64; from H = 128 on several tiles share
 // every fetch of the H x H table, which no longer fits a wave's registers: 16 accumulator tiles per wave).
 // In: [nslab][Hp][ldIn] fp32 (x fastest), S: [Hp][Hp] fp32 row-major, Fac: [XT*32][Hp] fp32 row-major.
-template <int NH> struct PostCfg { static constexpr int NXT = NH >= 8 ? 2 : (NH == 4 ? 4 : 1); };
+template <int NH> struct PostCfg { static constexpr int NXT = NH >= 8 ? 2 : 1; };    // (more tiles per wave at H = 128 are slower: 591 -> 830 us per 1M rows)
 
 template <int MODE, int NH>
 __global__ __launch_bounds__(256) void post_kernel(const float* __restrict__ In, long long ldIn, int nslab,
@@ -485,6 +485,118 @@ __global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ Cur
         o[idx] = g[r];
         o[(long long)Hp * Hp + idx] = d[r];
     }
+}
+
+// ---- Grams from the factor's OPERAND TILES with bf16 MFMAs (H >= 128, bf16 factor modes) ------------------------
+// The fp32 factor is exactly hi + lo (write_factor_tiles), and a tile's fragments are laid out "lane = column, 8
+// consecutive k per lane" -- which is BOTH the A- and the B-operand layout of v_mfma_f32_32x32x16_bf16 with the row
+// index as k.  So  F'F = hi'hi + hi'lo + lo'hi + lo'lo  is four bf16 MFMAs per tile pair and 16-row step straight from
+// the tiles (1 KiB wave loads), every product exact, fp32 accumulation as before: the same Gram at 1/16 of the MFMA time
+// of the exact-f32 path and without its 4-byte row gathers (measured at 100k x 256: 286 -> see DESIGN.md).
+// The delta-Gram needs d = old - new element-wise BEFORE squaring (src/util.jl:27-29 near convergence): old from the fp32
+// factor of the previous sweep, new from the tiles, d re-split into hi + lo (2^-17 relative on d).
+// One workgroup per chunk of tiles; wave w owns the upper-triangular tile pairs p = w (mod 4); slab format of gram_kernel.
+// WHAT = 0: the Gram only; 1: the delta-Gram only (two launches at H = 256: 9 pair tiles per wave and matrix, and both
+// matrices' accumulators together with the fragments would spill).
+template <int NH, int NPART, int WHAT>
+__global__ __launch_bounds__(256) void gram_tiles_kernel(const uint4* __restrict__ Ft, const float* __restrict__ Prev,
+                                                         float* __restrict__ slabs, int XT, int tiles_per_chunk,
+                                                         const int* __restrict__ stop) {
+    constexpr int Hp = NH * 32;
+    constexpr int NPAIR = NH * (NH + 1) / 2;
+    constexpr int PW = (NPAIR + 3) / 4;
+    if (stop && *stop) return;
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int c = lane & 31, half = lane >> 5;
+    const int chunk = blockIdx.x;
+    const u32x4v* F = reinterpret_cast<const u32x4v*>(Ft);
+    f32x16 G[PW];
+#pragma unroll
+    for (int q = 0; q < PW; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) G[q][r] = 0.f;
+    const int t0 = chunk * tiles_per_chunk;
+    const int t1 = min(XT, t0 + tiles_per_chunk);
+    for (int xt = t0; xt < t1; ++xt) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            u32x4v f[NH][NPART];
+#pragma unroll
+            for (int h = 0; h < NH; ++h)
+#pragma unroll
+                for (int pa = 0; pa < NPART; ++pa)
+                    f[h][pa] = F[(((long long)(2 * xt + s) * NPART + pa) * NH + h) * 64 + lane];
+            u32x4v dh[NH][2];
+            if constexpr (WHAT == 1) {
+                // each wave forms the difference fragments of NH/4 column tiles (the 4-byte row gathers of the old
+                // factor are the expensive part) and the workgroup shares them through LDS
+                __shared__ u32x4v dsh[NH][2][64];
+                __syncthreads();                                 // the previous step's fragments have been consumed
+#pragma unroll
+                for (int h = 0; h < NH; ++h) {
+                    if ((h & 3) != wib) continue;                // wave-uniform
+                    unsigned short hi[8], lo[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const unsigned hw = f[h][0][e >> 1];
+                        float v = bf2f((unsigned short)(hw >> (16 * (e & 1))));
+                        if constexpr (NPART == 2) v += bf2f((unsigned short)(f[h][1][e >> 1] >> (16 * (e & 1))));
+                        const float old = Prev[((long long)xt * 32 + rho(8 * s + e, half)) * Hp + h * 32 + c];
+                        const float d = old - v;
+                        hi[e] = f2bf(d);
+                        lo[e] = f2bf(d - bf2f(hi[e]));
+                    }
+                    dsh[h][0][lane] = u32x4v{hi[0] | ((unsigned)hi[1] << 16), hi[2] | ((unsigned)hi[3] << 16),
+                                             hi[4] | ((unsigned)hi[5] << 16), hi[6] | ((unsigned)hi[7] << 16)};
+                    dsh[h][1][lane] = u32x4v{lo[0] | ((unsigned)lo[1] << 16), lo[2] | ((unsigned)lo[3] << 16),
+                                             lo[4] | ((unsigned)lo[5] << 16), lo[6] | ((unsigned)lo[7] << 16)};
+                }
+                __syncthreads();
+#pragma unroll
+                for (int h = 0; h < NH; ++h) { dh[h][0] = dsh[h][0][lane]; dh[h][1] = dsh[h][1][lane]; }
+            }
+            int p = 0, q = 0;
+#pragma unroll
+            for (int h1 = 0; h1 < NH; ++h1)
+#pragma unroll
+                for (int h2 = h1; h2 < NH; ++h2, ++p) {
+                    if ((p & 3) != wib) continue;            // wave-uniform; p, q are compile-time per unrolled iteration
+                    const int qq = p >> 2;
+                    if constexpr (WHAT == 0) {
+#pragma unroll
+                        for (int pa = 0; pa < NPART; ++pa)
+#pragma unroll
+                            for (int pb = 0; pb < NPART; ++pb)
+                                G[qq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f[h1][pa]),
+                                                                                __builtin_bit_cast(bf16x8, f[h2][pb]), G[qq], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int pa = 0; pa < 2; ++pa)
+#pragma unroll
+                            for (int pb = 0; pb < 2; ++pb)
+                                G[qq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, dh[h1][pa]),
+                                                                                __builtin_bit_cast(bf16x8, dh[h2][pb]), G[qq], 0, 0, 0);
+                    }
+                    (void)q;
+                }
+        }
+    }
+    // accumulator (lane (half, c), register r) = element (row rho(r, half) of tile h1, column c of tile h2); both triangles
+    float* o = slabs + ((long long)chunk * 2 + WHAT) * Hp * Hp;
+    int p = 0;
+#pragma unroll
+    for (int h1 = 0; h1 < NH; ++h1)
+#pragma unroll
+        for (int h2 = h1; h2 < NH; ++h2, ++p) {
+            if ((p & 3) != wib) continue;
+            const int qq = p >> 2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long i = h1 * 32 + rho(r, half), j = h2 * 32 + c;
+                o[i * Hp + j] = G[qq][r];
+                if (h1 != h2) o[j * Hp + i] = G[qq][r];
+            }
+        }
 }
 
 // out[which][i] = sum_chunk slabs[chunk][which][i]  (fp64).  which in {0: Gram, 1: delta-Gram}.

@@ -338,7 +338,7 @@ static int launch_post(vbmf_ctx* c, int which, const float* In, int nslab) {
     uint4* Ft = which == 0 ? c->FA : c->FB;
     const unsigned char* mk = (which == 0 && c->has_mask) ? c->mask : nullptr;
     const int hstart = (int)(c->H - c->H1);
-    const int nxt = c->NH >= 8 ? 2 : (c->NH == 4 ? 4 : 1);       // = PostCfg<NH>::NXT
+    const int nxt = c->NH >= 8 ? 2 : 1;                          // = PostCfg<NH>::NXT
     const int grid = (cdiv(d.XT, nxt) + 3) / 4;
     DISPATCH_MODE(c->mode, DISPATCH_NH(c->NH, {
         hipLaunchKernelGGL((post_kernel<MODEc, NHc>), dim3(grid), dim3(256), 0, c->stream, In, ld, nslab, slabStride, S,
@@ -413,10 +413,28 @@ static int launch_gram(vbmf_ctx* c, int which, const float* cur, const float* pr
     const int nchunk = cdiv(d.XT, c->tiles_per_chunk);
     const int nw = nchunk * c->NH * c->NH;
     const int* stop = gated ? c->ints + I_STOP : nullptr;
-    DISPATCH_NH(c->NH, {
-        hipLaunchKernelGGL((gram_kernel<NHc>), dim3((nw + 3) / 4), dim3(256), 0, c->stream, cur, prev, c->gslab, d.XT,
-                           c->tiles_per_chunk, nchunk, stop);
-    });
+    // H >= 128 with a bf16 factor: from the operand tiles with bf16 MFMAs (the tiles of `cur` are current whenever a
+    // Gram of it is asked for: every producer of the fp32 factor writes them in the same kernel)
+    const bool from_tiles = c->NH >= 4 && c->mode != MODE_F32;
+    if (from_tiles) {
+        const uint4* Ft = which == 0 ? c->FA : c->FB;
+#define GRAM_TILES(NHc_, NPc_)                                                                                               \
+    do {                                                                                                                         \
+        hipLaunchKernelGGL((gram_tiles_kernel<NHc_, NPc_, 0>), dim3(nchunk), dim3(256), 0, c->stream, Ft, prev, c->gslab, d.XT,   \
+                           c->tiles_per_chunk, stop);                                                                            \
+        if (prev != nullptr)                                                                                                     \
+            hipLaunchKernelGGL((gram_tiles_kernel<NHc_, NPc_, 1>), dim3(nchunk), dim3(256), 0, c->stream, Ft, prev, c->gslab,      \
+                               d.XT, c->tiles_per_chunk, stop);                                                                  \
+    } while (0)
+        if (c->NH == 4) { if (c->npart == 2) GRAM_TILES(4, 2); else GRAM_TILES(4, 1); }
+        else { if (c->npart == 2) GRAM_TILES(8, 2); else GRAM_TILES(8, 1); }
+#undef GRAM_TILES
+    } else {
+        DISPATCH_NH(c->NH, {
+            hipLaunchKernelGGL((gram_kernel<NHc>), dim3((nw + 3) / 4), dim3(256), 0, c->stream, cur, prev, c->gslab, d.XT,
+                               c->tiles_per_chunk, nchunk, stop);
+        });
+    }
     const int n = c->Hp * c->Hp;
     const bool shard = (which == 1 && sharded(c));
     double* outG = shard ? c->gtmp : c->st + (which == 0 ? c->lay.GA() : c->lay.GB());
@@ -783,6 +801,9 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
     if (c->Hp == 96) c->Hp = 128;
     if (c->Hp > 128 && c->Hp < 256) c->Hp = 256;
     c->NH = c->Hp / 32;
+    // H >= 128: one Gram workgroup per chunk (gram_tiles_kernel): enough chunks to fill the chip, few enough that the
+    // fp64 reduction over the chunks' dense H x H slabs stays small (it was 412 us at 1M rows with 16-tile chunks)
+    c->tiles_per_chunk = c->NH >= 4 ? (int)std::max<int64_t>(16, cdiv(cdiv(std::max(L, M), 32), 384)) : 32;
     if (c->o.y_dtype == VBMF_Y_F32) {
         if (c->o.factor_dtype != VBMF_FACTOR_AUTO) { c->err = "f32 Y takes f32 factor operands (factor_dtype must be AUTO)"; return bail(VBMF_ERR_INVALID); }
         c->mode = MODE_F32;
