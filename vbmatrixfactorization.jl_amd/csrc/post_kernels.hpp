@@ -136,6 +136,74 @@ __global__ __launch_bounds__(256) void post_kernel(const float* __restrict__ In,
     }
 }
 
+// post_kernel for a FRAGMENT-MAJOR product (stream_gemm.hpp, frag_out; H >= 128, un-split pass): the product tile of
+// (x tile, h tile) arrives as this lane's 16 accumulator registers in four 16-byte loads; register t is the A operand
+// of MFMA step t, whose two k values are rows rho(t, half) of that h tile, so the table is read in that row order.
+template <int MODE, int NH>
+__global__ __launch_bounds__(256) void post_frag_kernel(const float4* __restrict__ In4, const float* __restrict__ S,
+                                                        float* __restrict__ Fac, uint4* __restrict__ Ft,
+                                                        const unsigned char* __restrict__ mask, int hmask_start, int XT,
+                                                        const int* __restrict__ stop) {
+    constexpr int Hp = NH * 32;
+    constexpr int NXT = PostCfg<NH>::NXT;
+    if (stop && *stop) return;
+    const int lane = threadIdx.x & 63;
+    const int xt0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * NXT;
+    if (xt0 >= XT) return;
+    const int c = lane & 31, half = lane >> 5;
+
+    f32x16 acc[NXT][NH];
+#pragma unroll
+    for (int i = 0; i < NXT; ++i)
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][h][r] = 0.f;
+
+    for (int hin = 0; hin < NH; ++hin) {
+        float a[NXT][16];
+#pragma unroll
+        for (int i = 0; i < NXT; ++i) {
+            const int xt = xt0 + i < XT ? xt0 + i : XT - 1;
+            const float4* t = In4 + (((long long)xt * NH + hin) * 64 + lane) * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = t[q];
+                a[i][4 * q] = v.x; a[i][4 * q + 1] = v.y; a[i][4 * q + 2] = v.z; a[i][4 * q + 3] = v.w;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {                            // fully unrolled: a[i][t] stays in registers
+            const int hk = hin * 32 + rho(t, half);
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                const float b = S[(long long)hk * Hp + h * 32 + c];
+#pragma unroll
+                for (int i = 0; i < NXT; ++i)
+                    acc[i][h] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b, acc[i][h], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NXT; ++i) {
+        const int xt = xt0 + i;
+        if (xt >= XT) break;
+        const long long x0 = (long long)xt * 32;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const int hcol = h * 32 + c;
+            if (mask != nullptr && hcol >= hmask_start) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (mask[x0 + rho(r, half)]) acc[i][h][r] = 0.f;
+            }
+            write_factor_tiles<MODE, NH>(Ft, acc[i][h], xt, h, lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Fac[(x0 + rho(r, half)) * Hp + hcol] = acc[i][h][r];
+        }
+    }
+}
+
 // ---- the inverse of write_factor_tiles: the fp32 factor values a tile's operand fragments encode (hi + lo) ------
 template <int MODE, int NH>
 __device__ __forceinline__ void read_factor_tiles(const uint4* __restrict__ Ft, f32x16& v, int xt, int nh, int lane) {

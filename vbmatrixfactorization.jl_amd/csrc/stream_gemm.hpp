@@ -57,6 +57,7 @@ struct EpiArgs {
     const int* sready; int expect;           // expect < 0: the table was complete before the launch
     int* err;
     int store_fac;                           // 0 inside vbmf_run: the fp32 factor is rebuilt from the tiles once, at the end
+    int frag_out;                            // EPI = 0 only: write the product in FRAGMENT-MAJOR order (below)
 };
 
 // FDBG (tuning harness only): 1 = the factor ring re-reads one L1-hot k-step, 2 = no factor refills at all
@@ -285,15 +286,29 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const uint4* __restric
         }
         float* o = epi.slabs + (long long)xb * (2 * NPAIR * 1024);
         for (int i = threadIdx.x; i < 2 * NPAIR * 1024; i += 256) o[i] = fold[i];
+    } else if (epi.frag_out) {
+        // Fragment-major product for the H >= 128 post kernel: tile (x tile, h tile) is 64 lanes x 16 registers, each lane's
+        // registers contiguous -- four 16-byte stores per tile here and four 16-byte loads there, instead of sixteen 4-byte
+        // row accesses on both sides (the consumer takes register r as the operand of MFMA step r: post_frag_kernel).
+        float4* o4 = reinterpret_cast<float4*>(Out + (long long)split * (NH * 32) * ldOut);
+#pragma unroll
+        for (int i = 0; i < NXW_; ++i)
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                float4* t = o4 + (((long long)(xg * NXW_ + i) * NH + h) * 64 + lane) * 4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    t[q] = float4{acc[i][h][4 * q], acc[i][h][4 * q + 1], acc[i][h][4 * q + 2], acc[i][h][4 * q + 3]};
+            }
     } else {
         const int c = lane & 31, half = lane >> 5;
         float* o = Out + (long long)split * (NH * 32) * ldOut;
-    #pragma unroll
+#pragma unroll
         for (int i = 0; i < NXW_; ++i) {
             const long long x = (long long)(xg * NXW_ + i) * 32 + c;
-    #pragma unroll
+#pragma unroll
             for (int h = 0; h < NH; ++h)
-    #pragma unroll
+#pragma unroll
                 for (int r = 0; r < 16; ++r) o[(long long)(h * 32 + rho(r, half)) * ldOut + x] = acc[i][h][r];
         }
     }

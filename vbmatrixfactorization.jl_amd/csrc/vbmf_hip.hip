@@ -267,7 +267,7 @@ static bool fused_ctrl(const vbmf_ctx* c) { return c->in_run && c->NH <= 4; }
 // ctrl_mode != 0: workgroup 0 of the launch runs that part of the control chain (CtrlArgs)
 // epi (pass 2 only, un-split, NH <= 2): B, its operand tiles and the Gram partials are produced in the kernel's register
 // epilogue (no separate post kernel); the caller then only reduces c->gslab over `*epi_slabs` workgroup slabs
-static int launch_stream(vbmf_ctx* c, int pass, int ctrl_mode = 0, bool epi = false, int* epi_slabs = nullptr) {
+static int launch_stream(vbmf_ctx* c, int pass, int ctrl_mode = 0, bool epi = false, int* epi_slabs = nullptr, bool frag_out = false) {
     const Dims& d = pass == 0 ? c->d1 : c->d2;
     const uint4* Y = pass == 0 ? c->Y1 : c->Y2;
     const uint4* F = pass == 0 ? (c->diagvar ? c->FBs : c->FB) : c->FA;
@@ -283,6 +283,7 @@ static int launch_stream(vbmf_ctx* c, int pass, int ctrl_mode = 0, bool epi = fa
     ca.H = (int)c->H; ca.spectral = (c->o.reference_compat & VBMF_COMPAT_SPECTRAL_DELTA) ? 1 : 0;
     ca.end_flags = c->run_flags; ca.mode = ctrl_mode; ca.it_row = (int)c->ends_enqueued;
     EpiArgs ea{};
+    ea.frag_out = frag_out ? 1 : 0;
     if (epi) {
         c->sready_seq = (c->sready_seq + 1) & 0x3fffffff;
         ea.S = c->SB32; ea.Fac = c->B32[c->bcur ^ 1]; ea.Prev = c->B32[c->bcur]; ea.Ft = c->FB; ea.slabs = c->gslab;
@@ -310,7 +311,7 @@ static int launch_stream(vbmf_ctx* c, int pass, int ctrl_mode = 0, bool epi = fa
         DISPATCH_MODE(c->mode, DISPATCH_NH(c->NH, {
             using Cfg = StreamCfg<NHc>;
             hipLaunchKernelGGL((stream_gemm_kernel<MODEc, NHc, Cfg::NXWc, Cfg::DYc, Cfg::DFc, Cfg::Rc>), dim3(grid), dim3(256), lds,
-                               c->stream, Y, F, out, XG, d.KS, d.steps_per_split, d.nsplit, ld, c->ints + I_STOP, ca, 0);
+                               c->stream, Y, F, out, XG, d.KS, d.steps_per_split, d.nsplit, ld, c->ints + I_STOP, ca, 0, ea);
         }));
     }
     prof_end(c);
@@ -352,6 +353,19 @@ static int launch_post(vbmf_ctx* c, int which, const float* In, int nslab) {
 static bool fused_gram(const vbmf_ctx* c) { return c->NH <= 2; }
 
 static int launch_pair_reduce(vbmf_ctx* c, int which, int nslab);
+
+// B from a fragment-major product (H >= 128, un-split Y*A pass)
+static int launch_post_frag(vbmf_ctx* c) {
+    const Dims& d = c->d2;
+    const int nxt = c->NH >= 8 ? 2 : 1;                          // = PostCfg<NH>::NXT
+    const int grid = (cdiv(d.XT, nxt) + 3) / 4;
+    DISPATCH_MODE(c->mode, {
+        if (c->NH == 4) hipLaunchKernelGGL((post_frag_kernel<MODEc, 4>), dim3(grid), dim3(256), 0, c->stream, (const float4*)c->Q, c->SB32, c->B32[c->bcur ^ 1], c->FB, (const unsigned char*)nullptr, 0, d.XT, c->ints + I_STOP);
+        else hipLaunchKernelGGL((post_frag_kernel<MODEc, 8>), dim3(grid), dim3(256), 0, c->stream, (const float4*)c->Q, c->SB32, c->B32[c->bcur ^ 1], c->FB, (const unsigned char*)nullptr, 0, d.XT, c->ints + I_STOP);
+    });
+    HIPCHK(c, hipGetLastError());
+    return VBMF_OK;
+}
 static int launch_post_gram(vbmf_ctx* c, int which, const float* In, int nslab) {
     const Dims& d = which == 0 ? c->d1 : c->d2;
     const long long ld = (long long)d.XT * 32;
@@ -651,23 +665,26 @@ static int do_update_B(vbmf_ctx* c) {
         c->kb_identity = true;
         return VBMF_OK;
     }
+    // H >= 128, un-split pass: the product travels fragment-major (16-byte accesses on both sides)
+    const bool fragq = !fused_gram(c) && c->d2.nsplit == 1;
     if (fused_ctrl(c)) {
-        TRY(launch_stream(c, 1, CTRL_COV_B | CTRL_EIG_BOLD));
+        TRY(launch_stream(c, 1, CTRL_COV_B | CTRL_EIG_BOLD, false, nullptr, fragq));
     } else if (side_overlap(c)) {
         TRY(side_fork(c));
         TRY(launch_ctrl_cov(c, 1));
         TRY(side_end(c));
-        TRY(launch_stream(c, 1));
+        TRY(launch_stream(c, 1, 0, false, nullptr, fragq));
     } else {
         TRY(launch_ctrl_cov(c, 1));
-        TRY(launch_stream(c, 1));
+        TRY(launch_stream(c, 1, 0, false, nullptr, fragq));
     }
     TRY(fold_Q_slabs(c));
     TRY(side_join(c));
     if (fused_gram(c)) {
         TRY(launch_post_gram(c, 1, c->Q, 1));
     } else {
-        TRY(launch_post(c, 1, c->Q, 1));
+        if (fragq) TRY(launch_post_frag(c));
+        else TRY(launch_post(c, 1, c->Q, 1));
         TRY(launch_gram(c, 1, c->B32[c->bcur ^ 1], c->B32[c->bcur], true));
     }
     c->bcur ^= 1;
@@ -1641,13 +1658,15 @@ static int do_sparse_update_B(vbmf_ctx* c) {
     } else {
         TRY(launch_sparse_cov_b(c));
     }
-    TRY(launch_stream(c, 1));
+    const bool fragq = !fused_gram(c) && c->d2.nsplit == 1 && !c->diagvar;   // (the row-noise update reads the plain product)
+    TRY(launch_stream(c, 1, 0, false, nullptr, fragq));
     TRY(fold_Q_slabs(c));
     TRY(side_join(c));
     if (fused_gram(c) && !c->diagvar) {
         TRY(launch_post_gram(c, 1, c->Q, 1));
     } else {
-        TRY(launch_post(c, 1, c->Q, 1));
+        if (fragq) TRY(launch_post_frag(c));
+        else TRY(launch_post(c, 1, c->Q, 1));
         // :261 -- B = diag(sigmaVecHat) * Y A SigmaB: the post kernel applied SigmaB, the rows are scaled here
         if (c->diagvar) TRY(launch_retile_ex(c, 1, c->B32[c->bcur ^ 1], c->FB, c->sig32, 1, true));
         TRY(launch_gram(c, 1, c->B32[c->bcur ^ 1], c->B32[c->bcur], true));
