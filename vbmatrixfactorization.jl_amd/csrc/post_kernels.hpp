@@ -313,7 +313,10 @@ __device__ __forceinline__ void post_gram_tile_regs(const f32x16 (&q)[NH], const
 // transpose, no LDS).  Waves walk tiles with stride gridDim*4; the four waves of a workgroup fold their
 // register partials through LDS into one slab per workgroup (upper-triangular tile pairs only).
 //   slabs: [gridDim.x][2 (Gram, delta)][NPAIR][16 regs][64 lanes] fp32
-template <int MODE, int NH>
+// FRAG: `In` is a FRAGMENT-MAJOR product (stream_gemm.hpp, frag_out: per (x tile, h tile) 64 lanes x 16 registers, a lane's
+// registers contiguous) -- read with four 16-byte loads per tile instead of sixteen 4-byte row accesses; register t is then
+// the A operand of MFMA step t, so the table is hoisted in the matching row order rho(t, half).
+template <int MODE, int NH, bool FRAG = false>
 __global__ __launch_bounds__(256) void post_gram_kernel(const float* __restrict__ In, long long ldIn, int nslab,
                                                         long long slabStride, const float* __restrict__ S,
                                                         float* __restrict__ Fac, const float* __restrict__ Prev,
@@ -342,22 +345,39 @@ __global__ __launch_bounds__(256) void post_gram_kernel(const float* __restrict_
 #pragma unroll
         for (int t = 0; t < 16; ++t)
 #pragma unroll
-            for (int h = 0; h < NH; ++h) sreg[hin][t][h] = S[(long long)(hin * 32 + 2 * t + half) * Hp + h * 32 + c];
+            for (int h = 0; h < NH; ++h)
+                sreg[hin][t][h] = S[(long long)(hin * 32 + (FRAG ? rho(t, half) : 2 * t + half)) * Hp + h * 32 + c];
 
     for (int xt = blockIdx.x * 4 + wib; xt < XT; xt += gridDim.x * 4) {
         const long long x0 = (long long)xt * 32;
         // issue every load of the tile before the first MFMA (one wave per SIMD: latency is hidden by
         // loads in flight, not by other waves)
         float areg[NH][16];
+        if constexpr (FRAG) {
 #pragma unroll
-        for (int hin = 0; hin < NH; ++hin)
+            for (int hin = 0; hin < NH; ++hin) {
+                const float4* ip = reinterpret_cast<const float4*>(In) + (((long long)xt * NH + hin) * 64 + lane) * 4;
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const float* ip = In + (long long)(hin * 32 + 2 * t + half) * ldIn + x0 + c;
-                float a = ip[0];
-                for (int s = 1; s < nslab; ++s) a += ip[(long long)s * slabStride];
-                areg[hin][t] = a;
+                for (int q = 0; q < 4; ++q) {
+                    float4 v = ip[q];
+                    for (int s = 1; s < nslab; ++s) {
+                        const float4 w = ip[(long long)s * (slabStride >> 2) + q];
+                        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+                    }
+                    areg[hin][4 * q] = v.x; areg[hin][4 * q + 1] = v.y; areg[hin][4 * q + 2] = v.z; areg[hin][4 * q + 3] = v.w;
+                }
             }
+        } else {
+#pragma unroll
+            for (int hin = 0; hin < NH; ++hin)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const float* ip = In + (long long)(hin * 32 + 2 * t + half) * ldIn + x0 + c;
+                    float a = ip[0];
+                    for (int s = 1; s < nslab; ++s) a += ip[(long long)s * slabStride];
+                    areg[hin][t] = a;
+                }
+        }
         f32x16 pv[NH];
         if (Prev != nullptr) {
 #pragma unroll
@@ -715,15 +735,22 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* slabs, int n
 }
 
 // *out += sum_{x<X, h<Hp} (sum_s In[s][h][x]) * Fac[x][h]
+// index of element (h, x) of a fragment-major product (stream_gemm.hpp, frag_out)
+__device__ __forceinline__ long long frag_index(int h, long long x, int NH) {
+    const int hr = h & 31, half = (hr >> 2) & 1, r = (hr & 3) + 4 * (hr >> 3);          // rho(r, half) == hr
+    return ((((x >> 5) * NH + (h >> 5)) * 64 + half * 32 + (int)(x & 31)) << 4) + r;
+}
+// frag_nh > 0: In is fragment-major with frag_nh = Hp / 32 column tiles
 __global__ __launch_bounds__(256) void dot_kernel(const float* __restrict__ In, long long ldIn, int nslab,
                                                   long long slabStride, const float* __restrict__ Fac, int Hp,
-                                                  long long X, double* __restrict__ out) {
+                                                  long long X, double* __restrict__ out, int frag_nh) {
     double acc = 0.0;
     for (long long x = (long long)blockIdx.x * blockDim.x + threadIdx.x; x < X;
          x += (long long)gridDim.x * blockDim.x) {
         for (int h = 0; h < Hp; ++h) {
             float a = 0.f;
-            for (int s = 0; s < nslab; ++s) a += In[(long long)s * slabStride + (long long)h * ldIn + x];
+            const long long e = frag_nh > 0 ? frag_index(h, x, frag_nh) : (long long)h * ldIn + x;
+            for (int s = 0; s < nslab; ++s) a += In[(long long)s * slabStride + e];
             acc += (double)a * (double)Fac[x * Hp + h];
         }
     }

@@ -90,6 +90,7 @@ struct vbmf_ctx {
     bool use_side = false, side_pending = false;
     bool in_run = false;              // inside vbmf_run: the control chain rides in workgroups 0-1 of the pass launches
     int gslab_cap = 256;
+    bool P_frag = false;              // the Y'B product in c->P / c->Pred is fragment-major (stream_gemm.hpp, frag_out)
     bool B32_stale = false;           // the register epilogue skipped the fp32 store of B (inside vbmf_run): tiles are current
     int sready_seq = 0;               // sequence number of the Sigma-table release flag (register epilogue)
     int64_t ends_enqueued = 0;        // sweeps whose closing control step has been enqueued in this run (trace row)
@@ -366,7 +367,7 @@ static int launch_post_frag(vbmf_ctx* c) {
     HIPCHK(c, hipGetLastError());
     return VBMF_OK;
 }
-static int launch_post_gram(vbmf_ctx* c, int which, const float* In, int nslab) {
+static int launch_post_gram(vbmf_ctx* c, int which, const float* In, int nslab, bool frag = false) {
     const Dims& d = which == 0 ? c->d1 : c->d2;
     const long long ld = (long long)d.XT * 32;
     const long long slabStride = (long long)c->Hp * ld;
@@ -379,8 +380,13 @@ static int launch_post_gram(vbmf_ctx* c, int which, const float* In, int nslab) 
     const int grid = std::min(256, (d.XT + 3) / 4);
     const int* stop = c->ints + I_STOP;
     DISPATCH_MODE(c->mode, {
-        if (c->NH == 1) hipLaunchKernelGGL((post_gram_kernel<MODEc, 1>), dim3(grid), dim3(256), 0, c->stream, In, ld, nslab, slabStride, S, Fac, Prev, Ft, mk, hstart, d.XT, c->gslab, stop);
-        else hipLaunchKernelGGL((post_gram_kernel<MODEc, 2>), dim3(grid), dim3(256), 0, c->stream, In, ld, nslab, slabStride, S, Fac, Prev, Ft, mk, hstart, d.XT, c->gslab, stop);
+        if (frag) {
+            if (c->NH == 1) hipLaunchKernelGGL((post_gram_kernel<MODEc, 1, true>), dim3(grid), dim3(256), 0, c->stream, In, ld, nslab, slabStride, S, Fac, Prev, Ft, mk, hstart, d.XT, c->gslab, stop);
+            else hipLaunchKernelGGL((post_gram_kernel<MODEc, 2, true>), dim3(grid), dim3(256), 0, c->stream, In, ld, nslab, slabStride, S, Fac, Prev, Ft, mk, hstart, d.XT, c->gslab, stop);
+        } else {
+            if (c->NH == 1) hipLaunchKernelGGL((post_gram_kernel<MODEc, 1>), dim3(grid), dim3(256), 0, c->stream, In, ld, nslab, slabStride, S, Fac, Prev, Ft, mk, hstart, d.XT, c->gslab, stop);
+            else hipLaunchKernelGGL((post_gram_kernel<MODEc, 2>), dim3(grid), dim3(256), 0, c->stream, In, ld, nslab, slabStride, S, Fac, Prev, Ft, mk, hstart, d.XT, c->gslab, stop);
+        }
     });
     return launch_pair_reduce(c, which, grid);
 }
@@ -586,7 +592,8 @@ static int do_update_A(vbmf_ctx* c, bool reuse_P = false) {
     if (have_P) {
         TRY(launch_ctrl_cov(c, 0));
     } else if (fused_ctrl(c)) {
-        TRY(launch_stream(c, 0, CTRL_COV_A | (c->tail_pending ? CTRL_PREV_END : 0)));
+        c->P_frag = fused_gram(c);           // H <= 64: Y'B travels fragment-major to post_gram (16-byte accesses)
+        TRY(launch_stream(c, 0, CTRL_COV_A | (c->tail_pending ? CTRL_PREV_END : 0), false, nullptr, c->P_frag));
         if (c->tail_pending) ++c->ends_enqueued;
         c->tail_pending = false;
         // SigmaA was computed speculatively beside the previous sweep's stop test: commit it iff the loop continues
@@ -605,7 +612,8 @@ static int do_update_A(vbmf_ctx* c, bool reuse_P = false) {
         TRY(launch_stream(c, 0));
     } else {
         TRY(launch_ctrl_cov(c, 0));
-        TRY(launch_stream(c, 0));
+        c->P_frag = fused_gram(c);
+        TRY(launch_stream(c, 0, 0, false, nullptr, c->P_frag));
     }
     if (sharded(c) || c->d1.nsplit > 1) {
         const long long n = (long long)c->Hp * c->d1.XT * 32;
@@ -621,11 +629,11 @@ static int do_update_A(vbmf_ctx* c, bool reuse_P = false) {
                 TRY(allreduce_sum(c, c->Pred, (size_t)n, false));
         }
         TRY(side_join(c));
-        if (fused_gram(c)) TRY(launch_post_gram(c, 0, c->Pred, 1));
+        if (fused_gram(c)) TRY(launch_post_gram(c, 0, c->Pred, 1, c->P_frag));
         else TRY(launch_post(c, 0, c->Pred, 1));
     } else {
         TRY(side_join(c));
-        if (fused_gram(c)) TRY(launch_post_gram(c, 0, c->P, 1));
+        if (fused_gram(c)) TRY(launch_post_gram(c, 0, c->P, 1, c->P_frag));
         else TRY(launch_post(c, 0, c->P, 1));
     }
     if (!fused_gram(c)) TRY(launch_gram(c, 0, c->A32, nullptr, true));
@@ -666,7 +674,8 @@ static int do_update_B(vbmf_ctx* c) {
         return VBMF_OK;
     }
     // H >= 128, un-split pass: the product travels fragment-major (16-byte accesses on both sides)
-    const bool fragq = !fused_gram(c) && c->d2.nsplit == 1;
+    // H <= 64 with a split pass (short row shards): fragment-major slabs, folded element-wise, read by post_gram
+    const bool fragq = (!fused_gram(c) && c->d2.nsplit == 1) || (fused_gram(c) && c->d2.nsplit > 1);
     if (fused_ctrl(c)) {
         TRY(launch_stream(c, 1, CTRL_COV_B | CTRL_EIG_BOLD, false, nullptr, fragq));
     } else if (side_overlap(c)) {
@@ -681,7 +690,7 @@ static int do_update_B(vbmf_ctx* c) {
     TRY(fold_Q_slabs(c));
     TRY(side_join(c));
     if (fused_gram(c)) {
-        TRY(launch_post_gram(c, 1, c->Q, 1));
+        TRY(launch_post_gram(c, 1, c->Q, 1, fragq));
     } else {
         if (fragq) TRY(launch_post_frag(c));
         else TRY(launch_post(c, 1, c->Q, 1));
@@ -704,12 +713,12 @@ static int prepare_trYBA(vbmf_ctx* c, int* flag) {
         const int ns = 1;
         const long long ld = (long long)c->d1.XT * 32;
         hipLaunchKernelGGL(dot_kernel, dim3(grid_for(c->M, 256, 1024)), dim3(256), 0, c->stream, In, ld, ns,
-                           (long long)c->Hp * ld, c->A32, c->Hp, (long long)c->M, dst);
+                           (long long)c->Hp * ld, c->A32, c->Hp, (long long)c->M, dst, c->P_frag ? c->NH : 0);
     } else {
         TRY(launch_stream(c, 1));
         const long long ld = (long long)c->d2.XT * 32;
         hipLaunchKernelGGL(dot_kernel, dim3(grid_for(c->L, 256, 1024)), dim3(256), 0, c->stream, c->Q, ld, c->d2.nsplit,
-                           (long long)c->Hp * ld, c->B32[c->bcur], c->Hp, (long long)c->L, dst);
+                           (long long)c->Hp * ld, c->B32[c->bcur], c->Hp, (long long)c->L, dst, 0);
         if (sharded(c)) TRY(allreduce_sum(c, dst, 1, true));
     }
     HIPCHK(c, hipGetLastError());
