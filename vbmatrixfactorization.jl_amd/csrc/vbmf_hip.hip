@@ -90,6 +90,7 @@ struct vbmf_ctx {
     bool use_side = false, side_pending = false;
     bool in_run = false;              // inside vbmf_run: the control chain rides in workgroups 0-1 of the pass launches
     int gslab_cap = 256;
+    bool xcd_map = true;              // XCD-aware work map for split-K pass launches (env VBMF_XCD_MAP=0 turns it off)
     bool P_frag = false;              // the Y'B product in c->P / c->Pred is fragment-major (stream_gemm.hpp, frag_out)
     bool B32_stale = false;           // the register epilogue skipped the fp32 store of B (inside vbmf_run): tiles are current
     int sready_seq = 0;               // sequence number of the Sigma-table release flag (register epilogue)
@@ -276,7 +277,9 @@ static int launch_stream(vbmf_ctx* c, int pass, int ctrl_mode = 0, bool epi = fa
     const long long ld = (long long)d.XT * 32;
     const int XG = d.XT / nxw_of(c->NH);
     const int bps = (XG + 3) / 4;
-    const int grid = bps * d.nsplit + (ctrl_mode ? 2 : 0);
+    // split-K launches use the XCD-aware work map (stream_gemm.hpp): 8 * per workgroups, per = ceil(blocks / 8)
+    const int xper = (d.nsplit > 1 && c->xcd_map) ? cdiv(bps * d.nsplit, 8) : 0;
+    const int grid = (xper ? 8 * xper : bps * d.nsplit) + (ctrl_mode ? 2 : 0);
     CtrlArgs ca{};
     ca.st = c->st; ca.lay = c->lay; ca.ints = c->ints; ca.trace = c->run_trace;
     ca.S32 = pass == 0 ? c->SA32 : c->SB32;
@@ -301,18 +304,18 @@ static int launch_stream(vbmf_ctx* c, int pass, int ctrl_mode = 0, bool epi = fa
             if (c->NH == 1) {
                 using Cfg = StreamCfg<1>;
                 hipLaunchKernelGGL((stream_gemm_kernel<MODEc, 1, Cfg::NXWc, Cfg::DYc, Cfg::DFc, Cfg::Rc, 0, 1>), dim3(grid), dim3(256), lds,
-                                   c->stream, Y, F, out, XG, d.KS, d.steps_per_split, d.nsplit, ld, c->ints + I_STOP, ca, 0, ea);
+                                   c->stream, Y, F, out, XG, d.KS, d.steps_per_split, d.nsplit, ld, c->ints + I_STOP, ca, xper, ea);
             } else {
                 using Cfg = StreamCfg<2>;
                 hipLaunchKernelGGL((stream_gemm_kernel<MODEc, 2, Cfg::NXWc, Cfg::DYc, Cfg::DFc, Cfg::Rc, 0, 1>), dim3(grid), dim3(256), lds,
-                                   c->stream, Y, F, out, XG, d.KS, d.steps_per_split, d.nsplit, ld, c->ints + I_STOP, ca, 0, ea);
+                                   c->stream, Y, F, out, XG, d.KS, d.steps_per_split, d.nsplit, ld, c->ints + I_STOP, ca, xper, ea);
             }
         });
     } else {
         DISPATCH_MODE(c->mode, DISPATCH_NH(c->NH, {
             using Cfg = StreamCfg<NHc>;
             hipLaunchKernelGGL((stream_gemm_kernel<MODEc, NHc, Cfg::NXWc, Cfg::DYc, Cfg::DFc, Cfg::Rc>), dim3(grid), dim3(256), lds,
-                               c->stream, Y, F, out, XG, d.KS, d.steps_per_split, d.nsplit, ld, c->ints + I_STOP, ca, 0, ea);
+                               c->stream, Y, F, out, XG, d.KS, d.steps_per_split, d.nsplit, ld, c->ints + I_STOP, ca, xper, ea);
         }));
     }
     prof_end(c);
@@ -827,6 +830,7 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
     if (c->Hp == 96) c->Hp = 128;
     if (c->Hp > 128 && c->Hp < 256) c->Hp = 256;
     c->NH = c->Hp / 32;
+    if (const char* e = getenv("VBMF_XCD_MAP")) c->xcd_map = atoi(e) != 0;      // A/B switch for the tuning record
     // H >= 128: one Gram workgroup per chunk (gram_tiles_kernel): enough chunks to fill the chip, few enough that the
     // fp64 reduction over the chunks' dense H x H slabs stays small (it was 412 us at 1M rows with 16-tile chunks)
     c->tiles_per_chunk = c->NH >= 4 ? (int)std::max<int64_t>(16, cdiv(cdiv(std::max(L, M), 32), 384)) : 32;
