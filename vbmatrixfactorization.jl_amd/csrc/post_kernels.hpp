@@ -21,8 +21,10 @@ namespace vbmf {
 // In the bf16 modes v is REPLACED by the value the tiles encode (hi, or hi+lo -- exactly representable
 // in fp32), so the fp32 factor kept for the Grams is bit-for-bit what the next MFMA pass multiplies:
 // the residual ||Y||^2 - 2tr(Y'BA') + tr(A'A B'B) then cancels consistently (src/vbmf.jl:154-156).
+// frags (bf16 modes, optional): the packed fragments as written, frags[2*s + part] for k-step s of the tile
 template <int MODE, int NH>
-__device__ __forceinline__ void write_factor_tiles(uint4* __restrict__ Ft, f32x16& v, int xt, int nh, int lane) {
+__device__ __forceinline__ void write_factor_tiles(uint4* __restrict__ Ft, f32x16& v, int xt, int nh, int lane,
+                                                   u32x4v* frags = nullptr) {
     constexpr int NPART = ModeTraits<MODE>::NPART;
     if constexpr (MODE == MODE_F32) {
 #pragma unroll
@@ -54,10 +56,12 @@ __device__ __forceinline__ void write_factor_tiles(uint4* __restrict__ Ft, f32x1
             o.z = hi[4] | ((unsigned)hi[5] << 16); o.w = hi[6] | ((unsigned)hi[7] << 16);
             const long long base = (long long)(2 * xt + s) * NPART;
             Ft[((base + 0) * NH + nh) * 64 + lane] = o;
+            if (frags) frags[2 * s] = u32x4v{o.x, o.y, o.z, o.w};
             if constexpr (NPART == 2) {
                 o.x = lo[0] | ((unsigned)lo[1] << 16); o.y = lo[2] | ((unsigned)lo[3] << 16);
                 o.z = lo[4] | ((unsigned)lo[5] << 16); o.w = lo[6] | ((unsigned)lo[7] << 16);
                 Ft[((base + 1) * NH + nh) * 64 + lane] = o;
+                if (frags) frags[2 * s + 1] = u32x4v{o.x, o.y, o.z, o.w};
             }
         }
     }
@@ -284,26 +288,71 @@ __device__ __forceinline__ void post_gram_tile_regs(const f32x16 (&q)[NH], const
                 const float a = q[hin][t];
                 acc[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, sperm[hin][t][h], acc[h], 0, 0, 0);
             }
+    // In the bf16 modes the new tile IS hi + lo, and its operand fragments (lane = column, 8 consecutive k per lane) are
+    // both operands of the bf16 MFMA with the row index as k: F'F = hi'hi + hi'lo + lo'hi + lo'lo, every product exact,
+    // at 1/8 of the exact-f32 MFMA time.  The delta d = old - new is re-split into hi + lo the same way (2^-17 on d).
+    u32x4v fr[NH][4];
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
-        write_factor_tiles<MODE, NH>(Ft, acc[h], xt, h, lane);
+        write_factor_tiles<MODE, NH>(Ft, acc[h], xt, h, lane, MODE == MODE_F32 ? nullptr : fr[h]);
         if (store_fac) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) Fac[(x0 + rho(r, half)) * Hp + h * 32 + c] = acc[h][r];
         }
     }
-    int p = 0;
+    if constexpr (MODE == MODE_F32) {
+        int p = 0;
 #pragma unroll
-    for (int h1 = 0; h1 < NH; ++h1)
+        for (int h1 = 0; h1 < NH; ++h1)
 #pragma unroll
-        for (int h2 = h1; h2 < NH; ++h2, ++p)
+            for (int h2 = h1; h2 < NH; ++h2, ++p)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float u = acc[h1][r], v = acc[h2][r];
-                G[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(u, v, G[p], 0, 0, 0);
-                const float du = pv[h1][r] - u, dv = pv[h2][r] - v;
-                D[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(du, dv, D[p], 0, 0, 0);
+                for (int r = 0; r < 16; ++r) {
+                    const float u = acc[h1][r], v = acc[h2][r];
+                    G[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(u, v, G[p], 0, 0, 0);
+                    const float du = pv[h1][r] - u, dv = pv[h2][r] - v;
+                    D[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(du, dv, D[p], 0, 0, 0);
+                }
+    } else {
+        constexpr int NPART = ModeTraits<MODE>::NPART;
+        u32x4v dr[NH][4];
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                unsigned short hi[8], lo[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d = pv[h][8 * s2 + e] - acc[h][8 * s2 + e];
+                    hi[e] = f2bf(d);
+                    lo[e] = f2bf(d - bf2f(hi[e]));
+                }
+                dr[h][2 * s2] = u32x4v{hi[0] | ((unsigned)hi[1] << 16), hi[2] | ((unsigned)hi[3] << 16),
+                                       hi[4] | ((unsigned)hi[5] << 16), hi[6] | ((unsigned)hi[7] << 16)};
+                dr[h][2 * s2 + 1] = u32x4v{lo[0] | ((unsigned)lo[1] << 16), lo[2] | ((unsigned)lo[3] << 16),
+                                           lo[4] | ((unsigned)lo[5] << 16), lo[6] | ((unsigned)lo[7] << 16)};
             }
+        int p = 0;
+#pragma unroll
+        for (int h1 = 0; h1 < NH; ++h1)
+#pragma unroll
+            for (int h2 = h1; h2 < NH; ++h2, ++p)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+                    for (int pa = 0; pa < NPART; ++pa)
+#pragma unroll
+                        for (int pb = 0; pb < NPART; ++pb)
+                            G[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fr[h1][2 * s2 + pa]),
+                                                                           __builtin_bit_cast(bf16x8, fr[h2][2 * s2 + pb]), G[p], 0, 0, 0);
+#pragma unroll
+                    for (int pa = 0; pa < 2; ++pa)
+#pragma unroll
+                        for (int pb = 0; pb < 2; ++pb)
+                            D[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, dr[h1][2 * s2 + pa]),
+                                                                           __builtin_bit_cast(bf16x8, dr[h2][2 * s2 + pb]), D[p], 0, 0, 0);
+                }
+    }
 }
 
 // ---- fused post + Gram (NH <= 2) ---------------------------------------------------------------------
