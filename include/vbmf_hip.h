@@ -50,6 +50,7 @@ typedef enum {
 #define VBMF_VARIANT_BASIC 0        /* src/vbmf.jl */
 #define VBMF_VARIANT_SPARSE_DIAG 1  /* src/vbmf_sparse.jl, full_cov=false, diag_var=false */
 #define VBMF_VARIANT_SPARSE_DIAGVAR 2 /* src/vbmf_sparse.jl, full_cov=false, diag_var=true: one noise precision per row */
+#define VBMF_VARIANT_DUAL_DIAG 3    /* src/vbmf_dual.jl, full_cov=false, diag_var=false: two column groups A = [A0 A1] */
 
 /* reference_compat bits (default: all set = behave like the reference) */
 #define VBMF_COMPAT_SPECTRAL_DELTA 1u  /* d uses operator 2-norms (src/util.jl:27-29, Julia 0.5 norm) */
@@ -143,6 +144,7 @@ typedef struct { double alpha0, beta0, gamma0, delta0, eta0, zeta0; } vbmf_spars
 #define VBMF_SSTEP_CA 4     /* updateCA!                 src/vbmf_sparse.jl:284-288 */
 #define VBMF_SSTEP_CB 8     /* updateCB!                 src/vbmf_sparse.jl:295-300 */
 #define VBMF_SSTEP_SIGMA 16 /* updateSigma! homoscedastic src/vbmf_sparse.jl:317-321 */
+#define VBMF_SSTEP_PRIORS 32 /* two-group model only, together with VBMF_SSTEP_CA: updateAlpha00!/01!, updateBeta00!/01!  src/vbmf_dual.jl:393-434 */
 
 int vbmf_sparse_set_state(vbmf_ctx* ctx, const double* ATVecHat, const double* diagSigmaATVec, const double* CA,
                           const double* beta, const double* BHat, int64_t ldB, const double* SigmaB,
@@ -167,6 +169,25 @@ int vbmf_sparse_run(vbmf_ctx* ctx, int64_t niter, double eps, int est_cb, int64_
 /* lowerBound (src/vbmf_sparse.jl:435-471), verbatim quirks QS4; H(B) as L*logdet(SigmaB), clamped like
  * normalEntropy's det (src/util.jl:118-122) when clamp != 0 */
 int vbmf_sparse_lower_bound(vbmf_ctx* ctx, int clamp, double* lb);
+
+/* ---- Two-group ARD variant (opts.variant = VBMF_VARIANT_DUAL_DIAG; src/vbmf_dual.jl, diagonal branch) -----------------
+ * vbmf_dual_parameters (src/vbmf_dual.jl:59-112): A = [A0 A1], H = H0 + H1; the element-wise precisions of columns
+ * h < H0 have the Gamma hyper-prior (alpha00, beta00), those of the other columns (alpha01, beta01); posterior shapes are
+ * alpha0g + 1/2 (:324-325).  updateA!/updateB!/updateCB!/updateSigma! are the sparse model's bodies (no label mask), so the
+ * state travels through vbmf_sparse_set_state / vbmf_sparse_get_state (CA and beta as the interleaved vectors of :146-165,
+ * hyper.alpha0/beta0 = the initial value of both groups' priors), and vbmf_sparse_step, vbmf_sparse_run_fixed_basis
+ * (vbls!, examples/mil_util.jl:190-193) and vbmf_sparse_lower_bound (lowerBound, src/vbmf_dual.jl:556-599) apply.
+ * set_priors: after vbmf_sparse_set_state; alpha0 / alpha1 are the posterior shapes the fields of those names hold (what
+ * the last updateCA! set; lowerBound reads them, :564-565).  get_priors: priors6 = {alpha00, beta00, alpha01, beta01, alpha0, alpha1}. */
+int vbmf_dual_set_priors(vbmf_ctx* ctx, int64_t H0, double alpha00, double beta00, double alpha01, double beta01,
+                         double alpha0, double alpha1);
+int vbmf_dual_get_priors(vbmf_ctx* ctx, int64_t* H0, double* priors6);
+/* vbmf_dual! loop (src/vbmf_dual.jl:455-530; convergence on BHat).  est_priors != 0 re-fits the four hyper-priors every
+ * sweep (:491-495) on the device: alpha0g = the root of the reference's fAlpha0g on its bracket [1e-10, 1e10] (the
+ * reference calls Roots.jl's fzero, a dependency it neither vendors nor pins: PARITY UNPINNED; unchanged when the bracket
+ * holds no sign change, like the reference's `try ... end`), beta0g = M*Hg*alpha0g / sum(CAg).  trace as vbmf_sparse_run. */
+int vbmf_dual_run(vbmf_ctx* ctx, int64_t niter, double eps, int est_cb, int est_priors, int64_t* iters_done,
+                  double* d_last, double* trace);
 
 /* ---- preprocess (src/util.jl:73-86; examples/mil_util.jl:829) fused into the upload -------------------------
  * scaleY (:36-54: row mean / sqrt(row variance, n-1), variance <= 1e-15 -> 1, |y - mu| <= 1e-8 -> 0), drop the rows whose

@@ -526,6 +526,203 @@ def lowerBound(Y, p, clamp=True):
 
 
 # ----------------------------------------------------------------------------------------------
+# Two-group ARD variant  (src/vbmf_dual.jl), diagonal branch (full_cov=false)
+#
+# A = [A0 A1] with H0 + H1 = H columns; each group has its own Gamma hyper-prior on the element-wise precisions
+# (alpha00, beta00 / alpha01, beta01) which `est_priors=true` re-fits every sweep by maximising the bound
+# (src/vbmf_dual.jl:393-434).  updateA!/updateB!/updateCB!/updateSigma! are the sparse model's bodies without the
+# label mask (:216-306, 358-386).  The fit of alpha00/alpha01 calls `fzero` of Roots.jl -- a third-party package that
+# is neither vendored nor pinned (it is absent from the reference's REQUIRE): PARITY UNPINNED for est_priors=true.
+# Restated as the exact root of the same monotone function on the same bracket [1e-10, 1e10]; like the reference's
+# `try ... end`, a bracket without a sign change leaves the value unchanged.
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class vbmf_dual_parameters(vbmf_sparse_parameters):
+    """src/vbmf_dual.jl:59-112.  Field names of the reference; `alpha`/`beta`/`CA` are the interleaved
+    (m, h) vectors of :146-165, CA0/CA1/beta0/beta1 the per-group ones (index (m-1)*H_g + h)."""
+    H0: int = 0
+    A0Hat: Optional[np.ndarray] = None
+    A1Hat: Optional[np.ndarray] = None
+    CA0: Optional[np.ndarray] = None
+    CA1: Optional[np.ndarray] = None
+    alpha00: float = 1e-10
+    beta00: float = 1e-10
+    alpha01: float = 1e-10
+    beta01: float = 1e-10
+    alpha1: float = 0.0
+    beta1: Optional[np.ndarray] = None
+    # NB: in this type `alpha0` is the POSTERIOR shape of group 0 and `beta0` its M*H0 rate vector (:31-32 of the
+    # reference's docstring); the scalar priors are alpha00/beta00.
+
+
+def _dual_split(vecMH, M, H, H0):
+    a = vecMH.reshape(M, H)
+    return a[:, :H0].reshape(M * H0).copy(), a[:, H0:].reshape(M * (H - H0)).copy()
+
+
+def _dual_join(v0, v1, M, H, H0):
+    return np.concatenate([v0.reshape(M, H0), v1.reshape(M, H - H0)], axis=1).reshape(M * H)
+
+
+def vbmf_dual_init(Y, H, H0, ca=1.0, alpha0=1e-10, beta0=1e-10, cb=1.0, gamma0=1e-10, delta0=1e-10,
+                   sigma=1.0, eta0=1e-10, zeta0=1e-10, rng=None, materialize_yhat=True):
+    """src/vbmf_dual.jl:122-193 (the two eye(MH) allocations of :141,143 are skipped: diagonal branch only)."""
+    if H < H0:
+        raise ValueError("H must be at least H0!")                       # :126-128
+    rng = np.random.default_rng(0) if rng is None else rng
+    p = vbmf_dual_parameters()
+    L, M = Y.shape
+    H1 = H - H0
+    p.L, p.M, p.H, p.MH, p.H0, p.H1 = L, M, H, M * H, H0, H1
+    p.AHat = rng.standard_normal((M, H))
+    p.ATVecHat = p.AHat.reshape(M * H).copy()
+    p.diagSigmaATVec = np.ones(M * H)
+    p.SigmaA = np.zeros((H, H))
+    p.A0Hat, p.A1Hat = p.AHat[:, :H0].copy(), p.AHat[:, H0:].copy()
+    p.BHat = rng.standard_normal((L, H))
+    p.SigmaB = np.zeros((H, H))
+    p.CA0, p.CA1 = ca * np.ones(M * H0), ca * np.ones(M * H1)
+    p.CA = _dual_join(p.CA0, p.CA1, M, H, H0)
+    p.alpha00 = p.alpha01 = alpha0
+    p.beta00 = p.beta01 = beta0
+    p.alpha0 = alpha0 + 0.5
+    p.alpha1 = alpha0 + 0.5
+    p.beta0, p.beta1 = beta0 * np.ones(M * H0), beta0 * np.ones(M * H1)
+    p.alpha = np.array([p.alpha0, p.alpha1])
+    p.beta = _dual_join(p.beta0, p.beta1, M, H, H0)
+    p.CB = cb * np.ones(H)
+    p.gamma0, p.delta0 = gamma0, delta0
+    p.gamma = gamma0 + L / 2
+    p.delta = delta0 * np.ones(H)
+    p.sigmaHat = float(sigma)
+    p.eta0, p.zeta0 = eta0, zeta0
+    p.eta = eta0 + L * M / 2
+    p.zeta = zeta0
+    p.sigmaVecHat = sigma * np.ones(L)
+    p.etaVec = (eta0 + M / 2) * np.ones(L)
+    p.zetaVec = zeta0 * np.ones(L)
+    p.YHat = p.BHat @ p.AHat.T if materialize_yhat else None
+    p.trYTY = traceXTY(Y, Y)
+    return p
+
+
+def dual_updateA(Y, p, reference_compat=True, diag_var=False):
+    """src/vbmf_dual.jl:245-284: the sparse model's diagonal branch, no label mask, then the A0/A1 views."""
+    sparse_updateA(Y, p, full_cov=False, reference_compat=reference_compat, diag_var=diag_var)
+    p.A0Hat, p.A1Hat = p.AHat[:, :p.H0].copy(), p.AHat[:, p.H0:].copy()
+
+
+def dual_updateCA(p):
+    """src/vbmf_dual.jl:322-351."""
+    M, H, H0 = p.M, p.H, p.H0
+    p.alpha0 = p.alpha00 + 0.5
+    p.alpha1 = p.alpha01 + 0.5
+    q0, q1 = _dual_split(p.ATVecHat * p.ATVecHat + p.diagSigmaATVec, M, H, H0)
+    p.beta0 = p.beta00 + 0.5 * q0
+    p.beta1 = p.beta01 + 0.5 * q1
+    p.CA0 = p.alpha0 / p.beta0
+    p.CA1 = p.alpha1 / p.beta1
+    p.CA = _dual_join(p.CA0, p.CA1, M, H, H0)
+    p.alpha = np.array([p.alpha0, p.alpha1])
+    p.beta = _dual_join(p.beta0, p.beta1, M, H, H0)
+
+
+def _dual_fit_shape(n, log_rate_prior, shape_post, rates, current):
+    """Root of  n*log(beta0g) - n*digamma(x) + sum_i gammaELn(shape_post, rates_i)  on [1e-10, 1e10]
+    (src/vbmf_dual.jl:394-400, 418-424)."""
+    from scipy.optimize import brentq
+    from scipy.special import digamma
+    if n == 0:
+        return current
+    s = float(np.sum(gammaELn(shape_post, rates)))
+    f = lambda x: n * log_rate_prior - n * float(digamma(x)) + s
+    lo, hi = 1e-10, 1e10
+    flo, fhi = f(lo), f(hi)
+    if not (np.isfinite(flo) and np.isfinite(fhi)) or flo * fhi > 0:
+        return current                                                   # fzero throws, `try ... end` swallows it
+    return float(brentq(f, lo, hi, xtol=1e-300, rtol=4 * np.finfo(float).eps, maxiter=500))
+
+
+def dual_updatePriors(p):
+    """updateAlpha00!, updateAlpha01!, updateBeta00!, updateBeta01! in the order of src/vbmf_dual.jl:491-495."""
+    n0, n1 = p.M * p.H0, p.M * p.H1
+    p.alpha00 = _dual_fit_shape(n0, math.log(p.beta00), p.alpha0, p.beta0, p.alpha00)
+    p.alpha01 = _dual_fit_shape(n1, math.log(p.beta01), p.alpha1, p.beta1, p.alpha01)
+    if n0:
+        p.beta00 = n0 * p.alpha00 / float(np.sum(p.CA0))                 # :408-410
+    if n1:
+        p.beta01 = n1 * p.alpha01 / float(np.sum(p.CA1))                 # :432-434
+
+
+def vbmf_dual_(Y, p, niter, eps=1e-6, est_cb=True, est_priors=True, reference_compat=True, diag_var=False, trace=None):
+    """vbmf_dual! -- src/vbmf_dual.jl:455-530 (full_cov=false, convergence on BHat).  Returns (d, iterations)."""
+    old = p.BHat.copy()
+    d = eps + 1.0
+    i = 1
+    while i <= niter and d > eps:
+        dual_updateA(Y, p, reference_compat=reference_compat, diag_var=diag_var)
+        sparse_updateB(Y, p, diag_var=diag_var)                          # :292-306
+        dual_updateCA(p)
+        if est_cb:
+            sparse_updateCB(p)                                           # :358-363
+        sparse_updateSigma(Y, p, diag_var=diag_var)                      # :370-386
+        if est_priors:
+            dual_updatePriors(p)
+        d = delta(p.BHat, old)
+        old = p.BHat.copy()
+        if trace is not None:
+            trace.append((d, p.sigmaHat, p.alpha00, p.beta00, p.alpha01, p.beta01))
+        i += 1
+    return d, i - 1
+
+
+def vbls_dual_(Y, p, niter, reference_compat=True):
+    """examples/mil_util.jl:190-193, vbmf_dual_parameters branch (full_cov=false, diag_var=false)."""
+    for _ in range(niter):
+        dual_updateA(Y, p, reference_compat=reference_compat)
+        dual_updateCA(p)
+        sparse_updateSigma(Y, p)
+    return p.AHat
+
+
+def lowerBound_dual(Y, p, clamp=True):
+    """src/vbmf_dual.jl:556-599 (homoscedastic), same sic's as the sparse bound; H(B) as L*logdet(SigmaB)."""
+    from scipy.special import gammaln
+    L_, M, H, H0, H1 = p.L, p.M, p.H, p.H0, p.H1
+    MH = p.ATVecHat.shape[0]
+    e0 = float(np.sum(gammaELn(p.alpha0, p.beta0))) if M * H0 else 0.0
+    e1 = float(np.sum(gammaELn(p.alpha1, p.beta1))) if M * H1 else 0.0
+    Lb = 0.0
+    Lb += -L_ * M / 2 * LN2PI + L_ * M / 2 * gammaELn(p.eta, p.zeta)
+    Lb += -p.sigmaHat / 2 * (p.trYTY - 2 * traceXTY(p.BHat, Y @ p.AHat)
+                             + traceXTY(p.AHat.T @ p.AHat + p.SigmaA, p.BHat.T @ p.BHat + L_ * p.SigmaB))
+    Lb += -MH / 2 * LN2PI + 0.5 * e0 + 0.5 * e1                                        # :564-565
+    Lb += -0.5 * float(p.CA @ (p.ATVecHat ** 2 + p.diagSigmaATVec))                    # :566
+    Lb += -L_ * H / 2 * LN2PI
+    eln_cb = gammaELn(p.gamma, p.delta)
+    Lb += L_ / 2 * float(np.sum(eln_cb))
+    Lb += -0.5 * traceXTY(np.diag(p.CB), p.BHat.T @ p.BHat + L_ * p.SigmaB)
+    Lb += p.eta0 * math.log(p.zeta0) - gammaln(p.eta0)
+    Lb += (p.eta0 - 1) * gammaELn(p.eta, p.zeta) - p.zeta0 * p.sigmaHat
+    Lb += M * H0 * (p.alpha00 * math.log(p.beta00) - gammaln(p.alpha00))               # :575-577
+    Lb += (p.alpha00 - 1) * e0 - p.beta00 * float(np.sum(p.CA0))
+    Lb += M * H1 * (p.alpha01 * math.log(p.beta01) - gammaln(p.alpha01))               # :579-581
+    Lb += (p.alpha01 - 1) * e1 - p.beta01 * float(np.sum(p.CA1))
+    Lb += H * (p.gamma0 * math.log(p.delta0) - gammaln(p.gamma0))
+    Lb += (p.gamma0 - 1) * float(np.sum(eln_cb))
+    Lb += -p.gamma0 * float(np.sum(p.CB))                                              # sic: gamma0 (:585)
+    Lb += normalEntropy_diag(p.diagSigmaATVec)
+    sgn, ld = np.linalg.slogdet(p.SigmaB)
+    logdet_kron = L_ * ld if sgn > 0 else -math.inf
+    Lb += normalEntropy_matrix_logdet(L_ * H, logdet_kron, clamp=clamp)
+    Lb += float(gammaEntropy(p.eta, p.zeta))
+    Lb += float(np.sum(gammaEntropy(p.alpha0, p.beta0))) if M * H0 else 0.0            # :593-596
+    Lb += float(np.sum(gammaEntropy(p.alpha1, p.beta1))) if M * H1 else 0.0
+    Lb += float(np.sum(gammaEntropy(p.gamma, p.delta)))
+    return float(Lb)
+
+
+# ----------------------------------------------------------------------------------------------
 # synthetic data (generalises toy_matrix, examples/toy_data.jl:7-18)
 # ----------------------------------------------------------------------------------------------
 def toy_matrix(L, M, H, std, rng):

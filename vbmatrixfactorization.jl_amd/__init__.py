@@ -34,13 +34,15 @@ from . import capi, dist
 from .data_manip import create_log, update_log_, save_log, load_log, extract_params_
 from .capi import PreprocessPlan
 from .capi import (Context, VbmfError, VBMF_Y_F32, VBMF_Y_BF16, VBMF_FACTOR_AUTO, VBMF_FACTOR_BF16,
-                   VBMF_FACTOR_BF16X2, VBMF_VARIANT_SPARSE_DIAG, VBMF_VARIANT_SPARSE_DIAGVAR, STEP_A, STEP_B, STEP_CA, STEP_CB, STEP_SIGMA2,
-                   SSTEP_A, SSTEP_B, SSTEP_CA, SSTEP_CB, SSTEP_SIGMA)
+                   VBMF_FACTOR_BF16X2, VBMF_VARIANT_SPARSE_DIAG, VBMF_VARIANT_SPARSE_DIAGVAR, VBMF_VARIANT_DUAL_DIAG, STEP_A, STEP_B, STEP_CA, STEP_CB, STEP_SIGMA2,
+                   SSTEP_A, SSTEP_B, SSTEP_CA, SSTEP_CB, SSTEP_SIGMA, SSTEP_PRIORS)
 
 __all__ = ["vbmf_parameters", "vbmf_init", "vbmf", "vbmf_", "copy", "updateA_", "updateB_", "updateCA_",
            "updateCB_", "updateSigma2_", "updateYHat_", "elbo", "Session", "set_defaults", "capi",
            "vbmf_sparse_parameters", "vbmf_sparse_init", "vbmf_sparse", "vbmf_sparse_", "lowerBound",
-           "sparse_updateA_", "sparse_updateB_", "sparse_updateCA_", "sparse_updateCB_", "sparse_updateSigma_"]
+           "sparse_updateA_", "sparse_updateB_", "sparse_updateCA_", "sparse_updateCB_", "sparse_updateSigma_",
+           "vbmf_dual_parameters", "vbmf_dual_init", "vbmf_dual", "vbmf_dual_", "lowerBound_dual", "dual_updateA_",
+           "dual_updateB_", "dual_updateCA_", "dual_updateCB_", "dual_updateSigma_", "dual_updateCA_and_priors_"]
 
 # YHat (L x M float64) is materialised eagerly by the reference (src/vbmf.jl:70,217); above this many
 # elements the field is left None and computed on demand with updateYHat_ (8 GB at 100k x 10k).
@@ -374,16 +376,18 @@ def vbmf_sparse_init(Y, H, ca=1.0, alpha0=1e-10, beta0=1e-10, cb=1.0, gamma0=1e-
 _sparse_sessions = {}
 
 
-def _sparse_ctx(Y, p, diag_var=False):
+def _sparse_ctx(Y, p, diag_var=False, dual=False):
     Y = np.asarray(Y, dtype=np.float64)
-    key = (id(Y), Y.shape, Y.__array_interface__["data"][0], int(p.H), bool(diag_var), tuple(sorted(_defaults.items())))
+    key = (id(Y), Y.shape, Y.__array_interface__["data"][0], int(p.H), bool(diag_var), bool(dual), tuple(sorted(_defaults.items())))
     ent = _sparse_sessions.get(key)
     if ent is not None and ent[1]() is Y:
         return ent[0]
     for k in list(_sparse_sessions):
         _sparse_sessions.pop(k)[0].close()
-    c = Context(Y.shape[0], Y.shape[1], p.H, variant=VBMF_VARIANT_SPARSE_DIAGVAR if diag_var else VBMF_VARIANT_SPARSE_DIAG,
-                **_defaults)
+    if dual and diag_var:
+        raise NotImplementedError("the two-group model is built for diag_var=false only")
+    variant = VBMF_VARIANT_DUAL_DIAG if dual else (VBMF_VARIANT_SPARSE_DIAGVAR if diag_var else VBMF_VARIANT_SPARSE_DIAG)
+    c = Context(Y.shape[0], Y.shape[1], p.H, variant=variant, **_defaults)
     c.set_Y(Y)
     _sparse_sessions[key] = (c, weakref.ref(Y))
     return c
@@ -490,6 +494,226 @@ def lowerBound(Y, params, clamp=True):
 
 
 # =================================================================================================
+# Two-group ARD variant -- src/vbmf_dual.jl with full_cov=false, diag_var=false
+# =================================================================================================
+@dataclass
+class vbmf_dual_parameters:
+    """src/vbmf_dual.jl:59-112 -- same field names and order (SigmaATVec/invSigmaATVec stay None: full_cov branch only).
+    NB the reference's naming: alpha0/alpha1 are the POSTERIOR shapes, beta0/beta1 the per-group rate vectors,
+    alpha00/beta00/alpha01/beta01 the scalar hyper-priors; CA/beta are the (m, h)-interleaved vectors of :146-165."""
+    L: int = 0
+    M: int = 0
+    MH: int = 0
+    H: int = 0
+    H0: int = 0
+    H1: int = 0
+    AHat: Optional[np.ndarray] = None
+    ATVecHat: Optional[np.ndarray] = None
+    SigmaATVec: Optional[np.ndarray] = None
+    diagSigmaATVec: Optional[np.ndarray] = None
+    invSigmaATVec: Optional[np.ndarray] = None
+    SigmaA: Optional[np.ndarray] = None
+    A0Hat: Optional[np.ndarray] = None
+    A1Hat: Optional[np.ndarray] = None
+    BHat: Optional[np.ndarray] = None
+    SigmaB: Optional[np.ndarray] = None
+    CA: Optional[np.ndarray] = None
+    alpha: Optional[np.ndarray] = None
+    beta: Optional[np.ndarray] = None
+    CA0: Optional[np.ndarray] = None
+    alpha00: float = 1e-10
+    beta00: float = 1e-10
+    alpha0: float = 0.0
+    beta0: Optional[np.ndarray] = None
+    CA1: Optional[np.ndarray] = None
+    alpha01: float = 1e-10
+    beta01: float = 1e-10
+    alpha1: float = 0.0
+    beta1: Optional[np.ndarray] = None
+    CB: Optional[np.ndarray] = None
+    gamma0: float = 1e-10
+    delta0: float = 1e-10
+    gamma: float = 0.0
+    delta: Optional[np.ndarray] = None
+    sigmaHat: float = 1.0
+    eta0: float = 1e-10
+    zeta0: float = 1e-10
+    eta: float = 0.0
+    zeta: float = 0.0
+    sigmaVecHat: Optional[np.ndarray] = None
+    etaVec: Optional[np.ndarray] = None
+    zetaVec: Optional[np.ndarray] = None
+    YHat: Optional[np.ndarray] = None
+    trYTY: float = 0.0
+
+
+def _dual_split(v, M, H, H0):
+    a = np.asarray(v).reshape(M, H)
+    return a[:, :H0].reshape(M * H0).copy(), a[:, H0:].reshape(M * (H - H0)).copy()
+
+
+def _dual_join(v0, v1, M, H, H0):
+    return np.concatenate([np.asarray(v0).reshape(M, H0), np.asarray(v1).reshape(M, H - H0)], axis=1).reshape(M * H)
+
+
+def vbmf_dual_init(Y, H, H0, ca=1.0, alpha0=1e-10, beta0=1e-10, cb=1.0, gamma0=1e-10, delta0=1e-10, sigma=1.0,
+                   eta0=1e-10, zeta0=1e-10, rng=None):
+    """src/vbmf_dual.jl:122-193 (host side)."""
+    if H < H0:
+        raise ValueError("H must be at least H0!")                        # :126-128
+    Y = np.asarray(Y)
+    rng = np.random.default_rng() if rng is None else rng
+    p = vbmf_dual_parameters()
+    L, M = Y.shape
+    H, H0 = int(H), int(H0)
+    H1 = H - H0
+    p.L, p.M, p.H, p.MH, p.H0, p.H1 = L, M, H, M * H, H0, H1
+    p.AHat = rng.standard_normal((M, H))
+    p.ATVecHat = p.AHat.reshape(M * H).copy()
+    p.diagSigmaATVec = np.ones(M * H)
+    p.SigmaA = np.zeros((H, H))
+    p.A0Hat, p.A1Hat = p.AHat[:, :H0].copy(), p.AHat[:, H0:].copy()
+    p.BHat = rng.standard_normal((L, H))
+    p.SigmaB = np.zeros((H, H))
+    p.CA0, p.CA1 = ca * np.ones(M * H0), ca * np.ones(M * H1)
+    p.CA = _dual_join(p.CA0, p.CA1, M, H, H0)
+    p.alpha00 = p.alpha01 = alpha0
+    p.beta00 = p.beta01 = beta0
+    p.alpha0 = p.alpha1 = alpha0 + 0.5
+    p.beta0, p.beta1 = beta0 * np.ones(M * H0), beta0 * np.ones(M * H1)
+    p.alpha = np.array([p.alpha0, p.alpha1])
+    p.beta = _dual_join(p.beta0, p.beta1, M, H, H0)
+    p.CB = cb * np.ones(H)
+    p.gamma0, p.delta0, p.gamma, p.delta = gamma0, delta0, gamma0 + L / 2, delta0 * np.ones(H)
+    p.sigmaHat, p.eta0, p.zeta0, p.eta, p.zeta = float(sigma), eta0, zeta0, eta0 + L * M / 2, zeta0
+    p.sigmaVecHat, p.etaVec, p.zetaVec = sigma * np.ones(L), (eta0 + M / 2) * np.ones(L), zeta0 * np.ones(L)
+    p.YHat = p.BHat @ p.AHat.T if L * M <= YHAT_AUTO_LIMIT else None
+    p.trYTY = float(np.sum(Y * Y))
+    return p
+
+
+def _dpush(c, p):
+    hyper = dict(alpha0=p.alpha00, beta0=p.beta00, gamma0=p.gamma0, delta0=p.delta0, eta0=p.eta0, zeta0=p.zeta0)
+    c.sparse_set_state(p.ATVecHat, p.diagSigmaATVec, p.CA, p.beta, p.BHat, p.SigmaB, p.CB, p.delta, p.sigmaHat, p.zeta, hyper)
+    c.dual_set_priors(p.H0, p.alpha00, p.beta00, p.alpha01, p.beta01, p.alpha0, p.alpha1)
+
+
+def _dpull(c, p):
+    s = c.sparse_get_state()
+    p.ATVecHat, p.diagSigmaATVec, p.CA, p.beta = s["ATVecHat"], s["diagSigmaATVec"], s["CA"], s["beta"]
+    p.AHat = p.ATVecHat.reshape(p.M, p.H).copy()
+    p.A0Hat, p.A1Hat = p.AHat[:, :p.H0].copy(), p.AHat[:, p.H0:].copy()
+    p.CA0, p.CA1 = _dual_split(p.CA, p.M, p.H, p.H0)
+    p.beta0, p.beta1 = _dual_split(p.beta, p.M, p.H, p.H0)
+    p.SigmaA = np.diag(s["SigmaA_diag"])
+    p.BHat, p.SigmaB, p.CB, p.delta = s["BHat"], s["SigmaB"], s["CB"], s["delta"]
+    p.sigmaHat, p.zeta = s["sigmaHat"], s["zeta"]
+    return s
+
+
+def _dpull_priors(c, p):
+    """The four hyper-priors and the posterior shapes alpha0/alpha1 as the last updateCA! set them (:324-325)."""
+    _, pr = c.dual_get_priors()
+    p.alpha00, p.beta00, p.alpha01, p.beta01 = float(pr["alpha00"]), float(pr["beta00"]), float(pr["alpha01"]), float(pr["beta01"])
+    p.alpha0, p.alpha1 = float(pr["alpha0"]), float(pr["alpha1"])
+    p.alpha = np.array([p.alpha0, p.alpha1])
+
+
+def _done(Y, p, which):
+    c = _sparse_ctx(Y, p, dual=True)
+    _dpush(c, p)
+    c.sparse_step(which)
+    _dpull(c, p)
+    _dpull_priors(c, p)
+
+
+def dual_updateA_(Y, params, full_cov=False, diag_var=False):
+    """updateA! -- src/vbmf_dual.jl:216-285 (diagonal branch, homoscedastic)."""
+    if full_cov or diag_var:
+        raise NotImplementedError("the two-group model is built for full_cov=false, diag_var=false")
+    _done(Y, params, SSTEP_A)
+
+
+def dual_updateB_(Y, params, diag_var=False):
+    """updateB! -- src/vbmf_dual.jl:292-306."""
+    if diag_var:
+        raise NotImplementedError("the two-group model is built for diag_var=false")
+    _done(Y, params, SSTEP_B)
+
+
+def dual_updateCA_(params, Y=None):
+    """updateCA! -- src/vbmf_dual.jl:322-351."""
+    _done(Y, params, SSTEP_CA)
+
+
+def dual_updateCB_(params, Y=None):
+    """updateCB! -- src/vbmf_dual.jl:358-363."""
+    _done(Y, params, SSTEP_CB)
+
+
+def dual_updateSigma_(Y, params, diag_var=False):
+    """updateSigma! -- src/vbmf_dual.jl:370-386 (homoscedastic)."""
+    if diag_var:
+        raise NotImplementedError("the two-group model is built for diag_var=false")
+    _done(Y, params, SSTEP_SIGMA)
+
+
+def dual_updateCA_and_priors_(params, Y=None):
+    """updateCA! followed by updateAlpha00!, updateAlpha01!, updateBeta00!, updateBeta01! (src/vbmf_dual.jl:393-434):
+    the fits read the group sums of the CA update, so the device does the pair in one call."""
+    _done(Y, params, SSTEP_CA | SSTEP_PRIORS)
+
+
+def vbmf_dual_(Y, params, niter, eps=1e-6, diag_var=False, full_cov=False, logdir="", desc="", verb=False, est_priors=True,
+               est_cb=True, log_every=1):
+    """vbmf_dual! -- src/vbmf_dual.jl:455-530.  Returns d (like the reference).  logdir: see vbmf_."""
+    if full_cov or diag_var:
+        raise NotImplementedError("the two-group model is built for full_cov=false, diag_var=false")
+    c = _sparse_ctx(Y, params, dual=True)
+    _dpush(c, params)
+    iters, d = 0, eps + 1.0
+    if logdir != "":
+        logVar = create_log(params)
+        i = 1
+        while i <= niter and d > eps:
+            k = int(min(max(1, log_every), niter - i + 1))
+            done, d, _ = c.dual_run(k, eps=eps, est_cb=est_cb, est_priors=est_priors)
+            _dpull(c, params)
+            _dpull_priors(c, params)
+            update_log_(logVar, params)
+            iters += done
+            i += done
+            if done < k:
+                break
+    else:
+        iters, d, _ = c.dual_run(int(niter), eps=eps, est_cb=est_cb, est_priors=est_priors)
+        _dpull(c, params)
+        _dpull_priors(c, params)
+    params.YHat = params.BHat @ params.AHat.T if params.L * params.M <= YHAT_AUTO_LIMIT else None   # :516
+    if verb:
+        print(f"Factorization finished after {iters} iterations, eps = {d}")
+    if logdir != "":
+        save_log(logVar, Y, {}, logdir, desc=desc)
+    params._last_run = (iters, d)
+    return d
+
+
+def vbmf_dual(Y, params_in, niter, **kw):
+    """vbmf_dual -- src/vbmf_dual.jl:538-549: deep-copies params_in (:200-208), returns (params, d)."""
+    import copy as _copy
+    p = _copy.deepcopy(params_in)
+    d = vbmf_dual_(Y, p, niter, **kw)
+    return p, d
+
+
+def lowerBound_dual(Y, params, clamp=True):
+    """lowerBound(Y, ::vbmf_dual_parameters) -- src/vbmf_dual.jl:556-599."""
+    c = _sparse_ctx(Y, params, dual=True)
+    _dpush(c, params)
+    return c.sparse_lower_bound(clamp=clamp)
+
+
+# =================================================================================================
 # Fixed-basis inference -- examples/mil_util.jl:179-236 (vbls!, copy_vbmf_params): the main caller of the
 # update functions outside vbmf!/vbmf_sparse! (150 resp. 20 iterations per bag in the MIL study,
 # examples/mil_util.jl:473-479,518-521)
@@ -500,6 +724,16 @@ def vbls_(Y, params, niter, diag_var=False, full_cov=False):
     On the device Y'B is formed once per call (B is fixed), so the call reads Y once, not 2 x niter times."""
     if full_cov:
         raise NotImplementedError("only full_cov=false is built (SURVEY.md section 2)")
+    if isinstance(params, vbmf_dual_parameters):                         # examples/mil_util.jl:190-193
+        if diag_var:
+            raise NotImplementedError("the two-group model is built for diag_var=false")
+        c = _sparse_ctx(Y, params, dual=True)
+        _dpush(c, params)
+        c.sparse_run_fixed_basis(int(niter))
+        _dpull(c, params)
+        _dpull_priors(c, params)
+        params.YHat = params.BHat @ params.AHat.T if params.L * params.M <= YHAT_AUTO_LIMIT else None
+        return params.AHat
     if isinstance(params, vbmf_sparse_parameters):
         c = _sparse_ctx(Y, params, diag_var)
         _spush(c, params, diag_var)
