@@ -51,6 +51,7 @@ typedef enum {
 #define VBMF_VARIANT_SPARSE_DIAG 1  /* src/vbmf_sparse.jl, full_cov=false, diag_var=false */
 #define VBMF_VARIANT_SPARSE_DIAGVAR 2 /* src/vbmf_sparse.jl, full_cov=false, diag_var=true: one noise precision per row */
 #define VBMF_VARIANT_DUAL_DIAG 3    /* src/vbmf_dual.jl, full_cov=false, diag_var=false: two column groups A = [A0 A1] */
+#define VBMF_VARIANT_TRIAL_DIAG 4   /* src/vbmf_trial.jl, full_cov=false, diag_var=false: three groups A = [A1 [A2; A3]] */
 
 /* reference_compat bits (default: all set = behave like the reference) */
 #define VBMF_COMPAT_SPECTRAL_DELTA 1u  /* d uses operator 2-norms (src/util.jl:27-29, Julia 0.5 norm) */
@@ -144,7 +145,7 @@ typedef struct { double alpha0, beta0, gamma0, delta0, eta0, zeta0; } vbmf_spars
 #define VBMF_SSTEP_CA 4     /* updateCA!                 src/vbmf_sparse.jl:284-288 */
 #define VBMF_SSTEP_CB 8     /* updateCB!                 src/vbmf_sparse.jl:295-300 */
 #define VBMF_SSTEP_SIGMA 16 /* updateSigma! homoscedastic src/vbmf_sparse.jl:317-321 */
-#define VBMF_SSTEP_PRIORS 32 /* two-group model only, together with VBMF_SSTEP_CA: updateAlpha00!/01!, updateBeta00!/01!  src/vbmf_dual.jl:393-434 */
+#define VBMF_SSTEP_PRIORS 32 /* grouped models only, together with VBMF_SSTEP_CA: updateAlpha0g!, updateBeta0g!  src/vbmf_dual.jl:393-434, src/vbmf_trial.jl:442-507 */
 
 int vbmf_sparse_set_state(vbmf_ctx* ctx, const double* ATVecHat, const double* diagSigmaATVec, const double* CA,
                           const double* beta, const double* BHat, int64_t ldB, const double* SigmaB,
@@ -188,6 +189,20 @@ int vbmf_dual_get_priors(vbmf_ctx* ctx, int64_t* H0, double* priors6);
  * holds no sign change, like the reference's `try ... end`), beta0g = M*Hg*alpha0g / sum(CAg).  trace as vbmf_sparse_run. */
 int vbmf_dual_run(vbmf_ctx* ctx, int64_t niter, double eps, int est_cb, int est_priors, int64_t* iters_done,
                   double* d_last, double* trace);
+
+/* ---- Three-group ARD variant (opts.variant = VBMF_VARIANT_TRIAL_DIAG; src/vbmf_trial.jl, diagonal branch) ---------------
+ * vbmf_trial_parameters (src/vbmf_trial.jl:68-131): A = [A1 [A2; A3]] -- A1 the first H0 columns (all M rows), A2 / A3 the
+ * other H1 columns of rows m < M0 / m >= M0; each block has its own Gamma hyper-prior (alpha0g, beta0g), g = 1, 2, 3
+ * (:357-400).  Everything else is the two-group model's: state through vbmf_sparse_set_state / get_state, updates through
+ * vbmf_sparse_step, vbls! through vbmf_sparse_run_fixed_basis (examples/mil_util.jl:194-197), lowerBound
+ * (src/vbmf_trial.jl:630-680) through vbmf_sparse_lower_bound.
+ * priors9 = {alpha01, beta01, alpha02, beta02, alpha03, beta03, alpha1, alpha2, alpha3} (the last three: the posterior shapes
+ * the fields alpha1..alpha3 hold).  vbmf_trial_run: the vbmf_trial! loop (:528-604), est_priors as in vbmf_dual_run. */
+int vbmf_trial_set_priors(vbmf_ctx* ctx, int64_t H0, int64_t M0, const double* priors9);
+int vbmf_trial_get_priors(vbmf_ctx* ctx, int64_t* H0, int64_t* M0, double* priors9);
+int vbmf_trial_run(vbmf_ctx* ctx, int64_t niter, double eps, int est_cb, int est_priors, int64_t* iters_done,
+                   double* d_last, double* trace);
+
 
 /* ---- preprocess (src/util.jl:73-86; examples/mil_util.jl:829) fused into the upload -------------------------
  * scaleY (:36-54: row mean / sqrt(row variance, n-1), variance <= 1e-15 -> 1, |y - mu| <= 1e-8 -> 0), drop the rows whose

@@ -723,6 +723,197 @@ def lowerBound_dual(Y, p, clamp=True):
 
 
 # ----------------------------------------------------------------------------------------------
+# Three-group ARD variant  (src/vbmf_trial.jl), diagonal branch (full_cov=false)
+#
+# A = [A1 [A2; A3]]: A1 = the first H0 columns (all rows), A2 / A3 = the other H1 columns of rows 1..M0 / M0+1..M, each
+# block with its own hyper-prior (alpha0g, beta0g).  updateA!/updateB!/updateCB!/updateSigma! are again the sparse
+# model's bodies (:250-341, 407-435); updateCA! and the fits are the two-group model's with one more group
+# (:357-400, 442-507).  Same `fzero` caveat: PARITY UNPINNED for est_priors=true.
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class vbmf_trial_parameters(vbmf_sparse_parameters):
+    """src/vbmf_trial.jl:68-131.  `alpha`/`beta`/`CA`: the interleaved (m, h) vectors of :178-211."""
+    M0: int = 0
+    M1: int = 0
+    H0: int = 0
+    A1Hat: Optional[np.ndarray] = None
+    A2Hat: Optional[np.ndarray] = None
+    A3Hat: Optional[np.ndarray] = None
+    CA1: Optional[np.ndarray] = None
+    CA2: Optional[np.ndarray] = None
+    CA3: Optional[np.ndarray] = None
+    alpha01: float = 1e-10
+    beta01: float = 1e-10
+    alpha02: float = 1e-10
+    beta02: float = 1e-10
+    alpha03: float = 1e-10
+    beta03: float = 1e-10
+    alpha1: float = 0.0
+    alpha2: float = 0.0
+    alpha3: float = 0.0
+    beta1: Optional[np.ndarray] = None
+    beta2: Optional[np.ndarray] = None
+    beta3: Optional[np.ndarray] = None
+
+
+def _trial_split(vecMH, M, H, H0, M0):
+    a = vecMH.reshape(M, H)
+    H1 = H - H0
+    return (a[:, :H0].reshape(M * H0).copy(), a[:M0, H0:].reshape(M0 * H1).copy(), a[M0:, H0:].reshape((M - M0) * H1).copy())
+
+
+def _trial_join(v1, v2, v3, M, H, H0, M0):
+    H1 = H - H0
+    right = np.concatenate([v2.reshape(M0, H1), v3.reshape(M - M0, H1)], axis=0)
+    return np.concatenate([v1.reshape(M, H0), right], axis=1).reshape(M * H)
+
+
+def vbmf_trial_init(Y, H, H0, M0, ca=1.0, alpha0=1e-10, beta0=1e-10, cb=1.0, gamma0=1e-10, delta0=1e-10,
+                    sigma=1.0, eta0=1e-10, zeta0=1e-10, rng=None, materialize_yhat=True):
+    """src/vbmf_trial.jl:139-226 (without the two eye(MH) allocations of :162,164)."""
+    if H < H0:
+        raise ValueError("H must be at least H0!")                       # :143-145
+    rng = np.random.default_rng(0) if rng is None else rng
+    p = vbmf_trial_parameters()
+    L, M = Y.shape
+    H1, M1 = H - H0, M - M0
+    p.L, p.M, p.H, p.MH, p.H0, p.H1, p.M0, p.M1 = L, M, H, M * H, H0, H1, M0, M1
+    p.AHat = rng.standard_normal((M, H))
+    p.ATVecHat = p.AHat.reshape(M * H).copy()
+    p.diagSigmaATVec = np.ones(M * H)
+    p.SigmaA = np.zeros((H, H))
+    p.A1Hat, p.A2Hat, p.A3Hat = p.AHat[:, :H0].copy(), p.AHat[:M0, H0:].copy(), p.AHat[M0:, H0:].copy()
+    p.BHat = rng.standard_normal((L, H))
+    p.SigmaB = np.zeros((H, H))
+    p.CA1, p.CA2, p.CA3 = ca * np.ones(M * H0), ca * np.ones(M0 * H1), ca * np.ones(M1 * H1)
+    p.CA = _trial_join(p.CA1, p.CA2, p.CA3, M, H, H0, M0)
+    p.alpha01 = p.alpha02 = p.alpha03 = alpha0
+    p.beta01 = p.beta02 = p.beta03 = beta0
+    p.alpha1 = p.alpha2 = p.alpha3 = alpha0 + 0.5
+    p.beta1, p.beta2, p.beta3 = beta0 * np.ones(M * H0), beta0 * np.ones(M0 * H1), beta0 * np.ones(M1 * H1)
+    p.alpha = np.array([p.alpha1, p.alpha2, p.alpha3])
+    p.beta = _trial_join(p.beta1, p.beta2, p.beta3, M, H, H0, M0)
+    p.CB = cb * np.ones(H)
+    p.gamma0, p.delta0 = gamma0, delta0
+    p.gamma = gamma0 + L / 2
+    p.delta = delta0 * np.ones(H)
+    p.sigmaHat = float(sigma)
+    p.eta0, p.zeta0 = eta0, zeta0
+    p.eta = eta0 + L * M / 2
+    p.zeta = zeta0
+    p.sigmaVecHat = sigma * np.ones(L)
+    p.etaVec = (eta0 + M / 2) * np.ones(L)
+    p.zetaVec = zeta0 * np.ones(L)
+    p.YHat = p.BHat @ p.AHat.T if materialize_yhat else None
+    p.trYTY = traceXTY(Y, Y)
+    return p
+
+
+def trial_updateA(Y, p, reference_compat=True, diag_var=False):
+    """src/vbmf_trial.jl:250-320: the sparse model's diagonal branch, no label mask, then the A1/A2/A3 views."""
+    sparse_updateA(Y, p, full_cov=False, reference_compat=reference_compat, diag_var=diag_var)
+    p.A1Hat, p.A2Hat, p.A3Hat = p.AHat[:, :p.H0].copy(), p.AHat[:p.M0, p.H0:].copy(), p.AHat[p.M0:, p.H0:].copy()
+
+
+def trial_updateCA(p):
+    """src/vbmf_trial.jl:357-400."""
+    M, H, H0, M0 = p.M, p.H, p.H0, p.M0
+    p.alpha1, p.alpha2, p.alpha3 = p.alpha01 + 0.5, p.alpha02 + 0.5, p.alpha03 + 0.5
+    q1, q2, q3 = _trial_split(p.ATVecHat * p.ATVecHat + p.diagSigmaATVec, M, H, H0, M0)
+    p.beta1 = p.beta01 + 0.5 * q1
+    p.beta2 = p.beta02 + 0.5 * q2
+    p.beta3 = p.beta03 + 0.5 * q3
+    p.CA1, p.CA2, p.CA3 = p.alpha1 / p.beta1, p.alpha2 / p.beta2, p.alpha3 / p.beta3
+    p.CA = _trial_join(p.CA1, p.CA2, p.CA3, M, H, H0, M0)
+    p.alpha = np.array([p.alpha1, p.alpha2, p.alpha3])
+    p.beta = _trial_join(p.beta1, p.beta2, p.beta3, M, H, H0, M0)
+
+
+def trial_updatePriors(p):
+    """updateAlpha01!..03!, then updateBeta01!..03! (src/vbmf_trial.jl:565-572, 442-507)."""
+    n = (p.M * p.H0, p.M0 * p.H1, p.M1 * p.H1)
+    p.alpha01 = _dual_fit_shape(n[0], math.log(p.beta01), p.alpha1, p.beta1, p.alpha01)
+    p.alpha02 = _dual_fit_shape(n[1], math.log(p.beta02), p.alpha2, p.beta2, p.alpha02)
+    p.alpha03 = _dual_fit_shape(n[2], math.log(p.beta03), p.alpha3, p.beta3, p.alpha03)
+    if n[0]:
+        p.beta01 = n[0] * p.alpha01 / float(np.sum(p.CA1))
+    if n[1]:
+        p.beta02 = n[1] * p.alpha02 / float(np.sum(p.CA2))
+    if n[2]:
+        p.beta03 = n[2] * p.alpha03 / float(np.sum(p.CA3))
+
+
+def vbmf_trial_(Y, p, niter, eps=1e-6, est_cb=True, est_priors=True, reference_compat=True, trace=None):
+    """vbmf_trial! -- src/vbmf_trial.jl:528-604 (full_cov=false, diag_var=false).  Returns (d, iterations)."""
+    old = p.BHat.copy()
+    d = eps + 1.0
+    i = 1
+    while i <= niter and d > eps:
+        trial_updateA(Y, p, reference_compat=reference_compat)
+        sparse_updateB(Y, p)                                             # :327-341
+        trial_updateCA(p)
+        if est_cb:
+            sparse_updateCB(p)                                           # :407-412
+        sparse_updateSigma(Y, p)                                         # :419-435
+        if est_priors:
+            trial_updatePriors(p)
+        d = delta(p.BHat, old)
+        old = p.BHat.copy()
+        if trace is not None:
+            trace.append((d, p.sigmaHat, p.alpha01, p.beta01, p.alpha02, p.beta02, p.alpha03, p.beta03))
+        i += 1
+    return d, i - 1
+
+
+def vbls_trial_(Y, p, niter, reference_compat=True):
+    """examples/mil_util.jl:194-197, vbmf_trial_parameters branch."""
+    for _ in range(niter):
+        trial_updateA(Y, p, reference_compat=reference_compat)
+        trial_updateCA(p)
+        sparse_updateSigma(Y, p)
+    return p.AHat
+
+
+def lowerBound_trial(Y, p, clamp=True):
+    """src/vbmf_trial.jl:630-680; H(B) as L*logdet(SigmaB)."""
+    from scipy.special import gammaln
+    L_, M, H = p.L, p.M, p.H
+    MH = p.ATVecHat.shape[0]
+    groups = [(p.M * p.H0, p.alpha01, p.beta01, p.alpha1, p.beta1, p.CA1),
+              (p.M0 * p.H1, p.alpha02, p.beta02, p.alpha2, p.beta2, p.CA2),
+              (p.M1 * p.H1, p.alpha03, p.beta03, p.alpha3, p.beta3, p.CA3)]
+    eln = [float(np.sum(gammaELn(ap, b))) if n else 0.0 for n, _, _, ap, b, _ in groups]
+    Lb = 0.0
+    Lb += -L_ * M / 2 * LN2PI + L_ * M / 2 * gammaELn(p.eta, p.zeta)
+    Lb += -p.sigmaHat / 2 * (p.trYTY - 2 * traceXTY(p.BHat, Y @ p.AHat)
+                             + traceXTY(p.AHat.T @ p.AHat + p.SigmaA, p.BHat.T @ p.BHat + L_ * p.SigmaB))
+    Lb += -MH / 2 * LN2PI + 0.5 * sum(eln)                                             # :637-639
+    Lb += -0.5 * float(p.CA @ (p.ATVecHat ** 2 + p.diagSigmaATVec))
+    Lb += -L_ * H / 2 * LN2PI
+    eln_cb = gammaELn(p.gamma, p.delta)
+    Lb += L_ / 2 * float(np.sum(eln_cb))
+    Lb += -0.5 * traceXTY(np.diag(p.CB), p.BHat.T @ p.BHat + L_ * p.SigmaB)
+    Lb += p.eta0 * math.log(p.zeta0) - gammaln(p.eta0)
+    Lb += (p.eta0 - 1) * gammaELn(p.eta, p.zeta) - p.zeta0 * p.sigmaHat
+    for (n, a0, b0, _, _, ca), e in zip(groups, eln):                                  # :649-659
+        if n:
+            Lb += n * (a0 * math.log(b0) - gammaln(a0)) + (a0 - 1) * e - b0 * float(np.sum(ca))
+    Lb += H * (p.gamma0 * math.log(p.delta0) - gammaln(p.gamma0))
+    Lb += (p.gamma0 - 1) * float(np.sum(eln_cb))
+    Lb += -p.gamma0 * float(np.sum(p.CB))                                              # sic: gamma0 (:663)
+    Lb += normalEntropy_diag(p.diagSigmaATVec)
+    sgn, ld = np.linalg.slogdet(p.SigmaB)
+    logdet_kron = L_ * ld if sgn > 0 else -math.inf
+    Lb += normalEntropy_matrix_logdet(L_ * H, logdet_kron, clamp=clamp)
+    Lb += float(gammaEntropy(p.eta, p.zeta))
+    for n, _, _, ap, b, _ in groups:                                                   # :671-676
+        if n:
+            Lb += float(np.sum(gammaEntropy(ap, b)))
+    Lb += float(np.sum(gammaEntropy(p.gamma, p.delta)))
+    return float(Lb)
+
+
+# ----------------------------------------------------------------------------------------------
 # synthetic data (generalises toy_matrix, examples/toy_data.jl:7-18)
 # ----------------------------------------------------------------------------------------------
 def toy_matrix(L, M, H, std, rng):

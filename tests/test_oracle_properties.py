@@ -171,3 +171,69 @@ def test_diagonal_branch_equals_full_branch_when_the_precision_is_diagonal_by_sh
         assert np.allclose(q.ATVecHat, full.ATVecHat, rtol=1e-10, atol=1e-14)
         assert np.allclose(q.diagSigmaATVec, full.diagSigmaATVec, rtol=1e-10)
         assert np.allclose(q.SigmaA, full.SigmaA, rtol=1e-10)
+
+
+# ---- grouped ARD variants (src/vbmf_dual.jl, src/vbmf_trial.jl) ---------------------------------
+def _toy(L=60, M=40, H=4, seed=1):
+    rng = np.random.default_rng(seed)
+    Y, _, _ = O.toy_matrix(L, M, H, 0.05, rng)
+    return Y
+
+
+def test_grouped_variants_reduce_to_each_other():
+    """vbmf_dual! without prior fits is vbmf_sparse! (same bodies, src/vbmf_dual.jl:216-386 vs src/vbmf_sparse.jl), and
+    vbmf_trial! with every row in the first block (M0 = M) is vbmf_dual!, prior fits and lowerBound included."""
+    Y = _toy()
+    pd = O.vbmf_dual_init(Y, 5, 3, ca=0.1, cb=0.1, sigma=0.1, rng=np.random.default_rng(3))
+    ps = O.vbmf_sparse_init(Y, 5, ca=0.1, cb=0.1, sigma=0.1, rng=np.random.default_rng(3), full_cov=False)
+    O.vbmf_dual_(Y, pd, 10, eps=0.0, est_priors=False)
+    O.vbmf_sparse_(Y, ps, 10, eps=0.0)
+    assert np.array_equal(pd.AHat, ps.AHat) and np.array_equal(pd.CA, ps.CA) and pd.sigmaHat == ps.sigmaHat
+    assert O.lowerBound_dual(Y, pd) == pytest.approx(O.lowerBound(Y, ps), rel=1e-13)
+    pt = O.vbmf_trial_init(Y, 5, 3, Y.shape[1], ca=0.1, cb=0.1, sigma=0.1, rng=np.random.default_rng(3))
+    pd = O.vbmf_dual_init(Y, 5, 3, ca=0.1, cb=0.1, sigma=0.1, rng=np.random.default_rng(3))
+    O.vbmf_trial_(Y, pt, 10, eps=0.0)
+    O.vbmf_dual_(Y, pd, 10, eps=0.0)
+    assert np.array_equal(pt.AHat, pd.AHat) and (pt.alpha01, pt.beta01, pt.alpha02, pt.beta02) == (pd.alpha00, pd.beta00, pd.alpha01, pd.beta01)
+    assert (pt.alpha03, pt.beta03) == (1e-10, 1e-10)                       # the empty block is never fitted
+    assert O.lowerBound_trial(Y, pt) == pytest.approx(O.lowerBound_dual(Y, pd), rel=1e-13)
+
+
+def test_grouped_layout_and_prior_fit_stationarity():
+    """The interleaved CA/beta vectors follow the reference's concatenation loops (src/vbmf_trial.jl:178-186), and each
+    fitted (alpha0g, beta0g) is a stationary point of the bound: digamma(alpha0g) = log(beta0g_old) + mean E[ln CA_g],
+    beta0g = n_g alpha0g / sum(CA_g) (src/vbmf_trial.jl:442-507)."""
+    from scipy.special import digamma
+    Y = _toy(50, 30, 4, 5)
+    M, H, H0, M0 = 30, 6, 2, 11
+    p = O.vbmf_trial_init(Y, H, H0, M0, ca=0.1, cb=0.1, sigma=0.1, rng=np.random.default_rng(9))
+    p.CA1, p.CA2, p.CA3 = 1.0 + np.arange(M * H0), 1000.0 + np.arange(M0 * (H - H0)), 5000.0 + np.arange((M - M0) * (H - H0))
+    ca = O._trial_join(p.CA1, p.CA2, p.CA3, M, H, H0, M0)
+    ref = []                                                               # the reference's loops, verbatim in spirit
+    H1 = H - H0
+    for m in range(1, M0 + 1):
+        ref += list(p.CA1[(m - 1) * H0:m * H0]) + list(p.CA2[(m - 1) * H1:m * H1])
+    for m in range(M0 + 1, M + 1):
+        ref += list(p.CA1[(m - 1) * H0:m * H0]) + list(p.CA3[(m - 1 - M0) * H1:(m - M0) * H1])
+    assert np.array_equal(ca, np.array(ref))
+    assert all(np.array_equal(a, b) for a, b in zip(O._trial_split(ca, M, H, H0, M0), (p.CA1, p.CA2, p.CA3)))
+    p = O.vbmf_trial_init(Y, H, H0, M0, ca=0.1, cb=0.1, sigma=0.1, rng=np.random.default_rng(9))
+    O.vbmf_trial_(Y, p, 3, eps=0.0, est_priors=True)
+    O.trial_updateA(Y, p); O.sparse_updateB(Y, p); O.trial_updateCA(p)
+    old = (p.beta01, p.beta02, p.beta03)
+    O.trial_updatePriors(p)
+    for n, a0, b0, b_old, ap, rates, cag in ((M * H0, p.alpha01, p.beta01, old[0], p.alpha1, p.beta1, p.CA1),
+                                            (M0 * H1, p.alpha02, p.beta02, old[1], p.alpha2, p.beta2, p.CA2),
+                                            ((M - M0) * H1, p.alpha03, p.beta03, old[2], p.alpha3, p.beta3, p.CA3)):
+        assert digamma(a0) == pytest.approx(np.log(b_old) + np.mean(O.gammaELn(ap, rates)), rel=1e-10, abs=1e-10)
+        assert b0 == pytest.approx(n * a0 / np.sum(cag), rel=1e-14)
+
+
+def test_grouped_prior_fit_keeps_the_value_without_a_sign_change():
+    """The reference wraps fzero in `try ... end` (src/vbmf_dual.jl:397-400): no root inside [1e-10, 1e10] -> unchanged."""
+    rates = np.full(12, 1e-30)                                             # E[ln CA] = digamma(a) + 69: root > 1e10
+    assert O._dual_fit_shape(12, np.log(1.0), 0.5, rates, 0.123) == 0.123
+    assert O._dual_fit_shape(0, 0.0, 0.5, np.zeros(0), 0.7) == 0.7         # empty group
+    x = O._dual_fit_shape(12, np.log(2.0), 1.5, np.full(12, 3.0), 0.123)
+    from scipy.special import digamma
+    assert digamma(x) == pytest.approx(np.log(2.0) + digamma(1.5) - np.log(3.0), rel=1e-12)

@@ -34,7 +34,7 @@ from . import capi, dist
 from .data_manip import create_log, update_log_, save_log, load_log, extract_params_
 from .capi import PreprocessPlan
 from .capi import (Context, VbmfError, VBMF_Y_F32, VBMF_Y_BF16, VBMF_FACTOR_AUTO, VBMF_FACTOR_BF16,
-                   VBMF_FACTOR_BF16X2, VBMF_VARIANT_SPARSE_DIAG, VBMF_VARIANT_SPARSE_DIAGVAR, VBMF_VARIANT_DUAL_DIAG, STEP_A, STEP_B, STEP_CA, STEP_CB, STEP_SIGMA2,
+                   VBMF_FACTOR_BF16X2, VBMF_VARIANT_SPARSE_DIAG, VBMF_VARIANT_SPARSE_DIAGVAR, VBMF_VARIANT_DUAL_DIAG, VBMF_VARIANT_TRIAL_DIAG, STEP_A, STEP_B, STEP_CA, STEP_CB, STEP_SIGMA2,
                    SSTEP_A, SSTEP_B, SSTEP_CA, SSTEP_CB, SSTEP_SIGMA, SSTEP_PRIORS)
 
 __all__ = ["vbmf_parameters", "vbmf_init", "vbmf", "vbmf_", "copy", "updateA_", "updateB_", "updateCA_",
@@ -42,7 +42,9 @@ __all__ = ["vbmf_parameters", "vbmf_init", "vbmf", "vbmf_", "copy", "updateA_", 
            "vbmf_sparse_parameters", "vbmf_sparse_init", "vbmf_sparse", "vbmf_sparse_", "lowerBound",
            "sparse_updateA_", "sparse_updateB_", "sparse_updateCA_", "sparse_updateCB_", "sparse_updateSigma_",
            "vbmf_dual_parameters", "vbmf_dual_init", "vbmf_dual", "vbmf_dual_", "lowerBound_dual", "dual_updateA_",
-           "dual_updateB_", "dual_updateCA_", "dual_updateCB_", "dual_updateSigma_", "dual_updateCA_and_priors_"]
+           "dual_updateB_", "dual_updateCA_", "dual_updateCB_", "dual_updateSigma_", "dual_updateCA_and_priors_",
+           "vbmf_trial_parameters", "vbmf_trial_init", "vbmf_trial", "vbmf_trial_", "lowerBound_trial", "trial_updateA_",
+           "trial_updateB_", "trial_updateCA_", "trial_updateCB_", "trial_updateSigma_", "trial_updateCA_and_priors_"]
 
 # YHat (L x M float64) is materialised eagerly by the reference (src/vbmf.jl:70,217); above this many
 # elements the field is left None and computed on demand with updateYHat_ (8 GB at 100k x 10k).
@@ -376,17 +378,17 @@ def vbmf_sparse_init(Y, H, ca=1.0, alpha0=1e-10, beta0=1e-10, cb=1.0, gamma0=1e-
 _sparse_sessions = {}
 
 
-def _sparse_ctx(Y, p, diag_var=False, dual=False):
+def _sparse_ctx(Y, p, diag_var=False, dual=False, trial=False):
     Y = np.asarray(Y, dtype=np.float64)
-    key = (id(Y), Y.shape, Y.__array_interface__["data"][0], int(p.H), bool(diag_var), bool(dual), tuple(sorted(_defaults.items())))
+    key = (id(Y), Y.shape, Y.__array_interface__["data"][0], int(p.H), bool(diag_var), bool(dual), bool(trial), tuple(sorted(_defaults.items())))
     ent = _sparse_sessions.get(key)
     if ent is not None and ent[1]() is Y:
         return ent[0]
     for k in list(_sparse_sessions):
         _sparse_sessions.pop(k)[0].close()
-    if dual and diag_var:
-        raise NotImplementedError("the two-group model is built for diag_var=false only")
-    variant = VBMF_VARIANT_DUAL_DIAG if dual else (VBMF_VARIANT_SPARSE_DIAGVAR if diag_var else VBMF_VARIANT_SPARSE_DIAG)
+    if (dual or trial) and diag_var:
+        raise NotImplementedError("the grouped models are built for diag_var=false only")
+    variant = VBMF_VARIANT_TRIAL_DIAG if trial else (VBMF_VARIANT_DUAL_DIAG if dual else (VBMF_VARIANT_SPARSE_DIAGVAR if diag_var else VBMF_VARIANT_SPARSE_DIAG))
     c = Context(Y.shape[0], Y.shape[1], p.H, variant=variant, **_defaults)
     c.set_Y(Y)
     _sparse_sessions[key] = (c, weakref.ref(Y))
@@ -714,6 +716,229 @@ def lowerBound_dual(Y, params, clamp=True):
 
 
 # =================================================================================================
+# Three-group ARD variant -- src/vbmf_trial.jl with full_cov=false, diag_var=false
+# =================================================================================================
+@dataclass
+class vbmf_trial_parameters:
+    """src/vbmf_trial.jl:68-131 -- same field names and order (SigmaATVec/invSigmaATVec stay None).  alpha1..alpha3 are
+    the posterior shapes, beta1..beta3 the per-group rate vectors, alpha0g/beta0g the scalar hyper-priors."""
+    L: int = 0
+    M: int = 0
+    M0: int = 0
+    M1: int = 0
+    MH: int = 0
+    H: int = 0
+    H0: int = 0
+    H1: int = 0
+    AHat: Optional[np.ndarray] = None
+    ATVecHat: Optional[np.ndarray] = None
+    SigmaATVec: Optional[np.ndarray] = None
+    diagSigmaATVec: Optional[np.ndarray] = None
+    invSigmaATVec: Optional[np.ndarray] = None
+    SigmaA: Optional[np.ndarray] = None
+    A1Hat: Optional[np.ndarray] = None
+    A2Hat: Optional[np.ndarray] = None
+    A3Hat: Optional[np.ndarray] = None
+    BHat: Optional[np.ndarray] = None
+    SigmaB: Optional[np.ndarray] = None
+    CA: Optional[np.ndarray] = None
+    alpha: Optional[np.ndarray] = None
+    beta: Optional[np.ndarray] = None
+    CA1: Optional[np.ndarray] = None
+    alpha01: float = 1e-10
+    beta01: float = 1e-10
+    alpha1: float = 0.0
+    beta1: Optional[np.ndarray] = None
+    CA2: Optional[np.ndarray] = None
+    alpha02: float = 1e-10
+    beta02: float = 1e-10
+    alpha2: float = 0.0
+    beta2: Optional[np.ndarray] = None
+    CA3: Optional[np.ndarray] = None
+    alpha03: float = 1e-10
+    beta03: float = 1e-10
+    alpha3: float = 0.0
+    beta3: Optional[np.ndarray] = None
+    CB: Optional[np.ndarray] = None
+    gamma0: float = 1e-10
+    delta0: float = 1e-10
+    gamma: float = 0.0
+    delta: Optional[np.ndarray] = None
+    sigmaHat: float = 1.0
+    eta0: float = 1e-10
+    zeta0: float = 1e-10
+    eta: float = 0.0
+    zeta: float = 0.0
+    sigmaVecHat: Optional[np.ndarray] = None
+    etaVec: Optional[np.ndarray] = None
+    zetaVec: Optional[np.ndarray] = None
+    YHat: Optional[np.ndarray] = None
+    trYTY: float = 0.0
+
+
+def _trial_split(v, M, H, H0, M0):
+    a = np.asarray(v).reshape(M, H)
+    H1 = H - H0
+    return (a[:, :H0].reshape(M * H0).copy(), a[:M0, H0:].reshape(M0 * H1).copy(), a[M0:, H0:].reshape((M - M0) * H1).copy())
+
+
+def _trial_join(v1, v2, v3, M, H, H0, M0):
+    H1 = H - H0
+    right = np.concatenate([np.asarray(v2).reshape(M0, H1), np.asarray(v3).reshape(M - M0, H1)], axis=0)
+    return np.concatenate([np.asarray(v1).reshape(M, H0), right], axis=1).reshape(M * H)
+
+
+def vbmf_trial_init(Y, H, H0, M0, ca=1.0, alpha0=1e-10, beta0=1e-10, cb=1.0, gamma0=1e-10, delta0=1e-10, sigma=1.0,
+                    eta0=1e-10, zeta0=1e-10, rng=None):
+    """src/vbmf_trial.jl:139-226 (host side)."""
+    if H < H0:
+        raise ValueError("H must be at least H0!")                        # :143-145
+    Y = np.asarray(Y)
+    rng = np.random.default_rng() if rng is None else rng
+    p = vbmf_trial_parameters()
+    L, M = Y.shape
+    H, H0, M0 = int(H), int(H0), int(M0)
+    if not 0 <= M0 <= M:
+        raise ValueError("M0 must lie in 0..M")
+    H1, M1 = H - H0, M - M0
+    p.L, p.M, p.H, p.MH, p.H0, p.H1, p.M0, p.M1 = L, M, H, M * H, H0, H1, M0, M1
+    p.AHat = rng.standard_normal((M, H))
+    p.ATVecHat = p.AHat.reshape(M * H).copy()
+    p.diagSigmaATVec = np.ones(M * H)
+    p.SigmaA = np.zeros((H, H))
+    p.A1Hat, p.A2Hat, p.A3Hat = p.AHat[:, :H0].copy(), p.AHat[:M0, H0:].copy(), p.AHat[M0:, H0:].copy()
+    p.BHat = rng.standard_normal((L, H))
+    p.SigmaB = np.zeros((H, H))
+    p.CA1, p.CA2, p.CA3 = ca * np.ones(M * H0), ca * np.ones(M0 * H1), ca * np.ones(M1 * H1)
+    p.CA = _trial_join(p.CA1, p.CA2, p.CA3, M, H, H0, M0)
+    p.alpha01 = p.alpha02 = p.alpha03 = alpha0
+    p.beta01 = p.beta02 = p.beta03 = beta0
+    p.alpha1 = p.alpha2 = p.alpha3 = alpha0 + 0.5
+    p.beta1, p.beta2, p.beta3 = beta0 * np.ones(M * H0), beta0 * np.ones(M0 * H1), beta0 * np.ones(M1 * H1)
+    p.alpha = np.array([p.alpha1, p.alpha2, p.alpha3])
+    p.beta = _trial_join(p.beta1, p.beta2, p.beta3, M, H, H0, M0)
+    p.CB = cb * np.ones(H)
+    p.gamma0, p.delta0, p.gamma, p.delta = gamma0, delta0, gamma0 + L / 2, delta0 * np.ones(H)
+    p.sigmaHat, p.eta0, p.zeta0, p.eta, p.zeta = float(sigma), eta0, zeta0, eta0 + L * M / 2, zeta0
+    p.sigmaVecHat, p.etaVec, p.zetaVec = sigma * np.ones(L), (eta0 + M / 2) * np.ones(L), zeta0 * np.ones(L)
+    p.YHat = p.BHat @ p.AHat.T if L * M <= YHAT_AUTO_LIMIT else None
+    p.trYTY = float(np.sum(Y * Y))
+    return p
+
+
+def _tpush(c, p):
+    hyper = dict(alpha0=p.alpha01, beta0=p.beta01, gamma0=p.gamma0, delta0=p.delta0, eta0=p.eta0, zeta0=p.zeta0)
+    c.sparse_set_state(p.ATVecHat, p.diagSigmaATVec, p.CA, p.beta, p.BHat, p.SigmaB, p.CB, p.delta, p.sigmaHat, p.zeta, hyper)
+    c.trial_set_priors(p.H0, p.M0, {k: getattr(p, k) for k in Context.TRIAL_KEYS})
+
+
+def _tpull(c, p):
+    s = c.sparse_get_state()
+    p.ATVecHat, p.diagSigmaATVec, p.CA, p.beta = s["ATVecHat"], s["diagSigmaATVec"], s["CA"], s["beta"]
+    p.AHat = p.ATVecHat.reshape(p.M, p.H).copy()
+    p.A1Hat, p.A2Hat, p.A3Hat = p.AHat[:, :p.H0].copy(), p.AHat[:p.M0, p.H0:].copy(), p.AHat[p.M0:, p.H0:].copy()
+    p.CA1, p.CA2, p.CA3 = _trial_split(p.CA, p.M, p.H, p.H0, p.M0)
+    p.beta1, p.beta2, p.beta3 = _trial_split(p.beta, p.M, p.H, p.H0, p.M0)
+    p.SigmaA = np.diag(s["SigmaA_diag"])
+    p.BHat, p.SigmaB, p.CB, p.delta = s["BHat"], s["SigmaB"], s["CB"], s["delta"]
+    p.sigmaHat, p.zeta = s["sigmaHat"], s["zeta"]
+    _, _, pr = c.trial_get_priors()
+    for k, v in pr.items():
+        setattr(p, k, v)
+    p.alpha = np.array([p.alpha1, p.alpha2, p.alpha3])
+
+
+def _tone(Y, p, which):
+    c = _sparse_ctx(Y, p, trial=True)
+    _tpush(c, p)
+    c.sparse_step(which)
+    _tpull(c, p)
+
+
+def trial_updateA_(Y, params, full_cov=False, diag_var=False):
+    """updateA! -- src/vbmf_trial.jl:250-320 (diagonal branch, homoscedastic)."""
+    if full_cov or diag_var:
+        raise NotImplementedError("the three-group model is built for full_cov=false, diag_var=false")
+    _tone(Y, params, SSTEP_A)
+
+
+def trial_updateB_(Y, params, diag_var=False):
+    """updateB! -- src/vbmf_trial.jl:327-341."""
+    if diag_var:
+        raise NotImplementedError("the three-group model is built for diag_var=false")
+    _tone(Y, params, SSTEP_B)
+
+
+def trial_updateCA_(params, Y=None):
+    """updateCA! -- src/vbmf_trial.jl:357-400."""
+    _tone(Y, params, SSTEP_CA)
+
+
+def trial_updateCB_(params, Y=None):
+    """updateCB! -- src/vbmf_trial.jl:407-412."""
+    _tone(Y, params, SSTEP_CB)
+
+
+def trial_updateSigma_(Y, params, diag_var=False):
+    """updateSigma! -- src/vbmf_trial.jl:419-435 (homoscedastic)."""
+    if diag_var:
+        raise NotImplementedError("the three-group model is built for diag_var=false")
+    _tone(Y, params, SSTEP_SIGMA)
+
+
+def trial_updateCA_and_priors_(params, Y=None):
+    """updateCA! followed by updateAlpha01!..03!, updateBeta01!..03! (src/vbmf_trial.jl:442-507)."""
+    _tone(Y, params, SSTEP_CA | SSTEP_PRIORS)
+
+
+def vbmf_trial_(Y, params, niter, eps=1e-6, diag_var=False, full_cov=False, logdir="", desc="", verb=False, est_priors=True,
+                est_cb=True, log_every=1):
+    """vbmf_trial! -- src/vbmf_trial.jl:528-604.  Returns d (like the reference).  logdir: see vbmf_."""
+    if full_cov or diag_var:
+        raise NotImplementedError("the three-group model is built for full_cov=false, diag_var=false")
+    c = _sparse_ctx(Y, params, trial=True)
+    _tpush(c, params)
+    iters, d = 0, eps + 1.0
+    if logdir != "":
+        logVar = create_log(params)
+        i = 1
+        while i <= niter and d > eps:
+            k = int(min(max(1, log_every), niter - i + 1))
+            done, d, _ = c.trial_run(k, eps=eps, est_cb=est_cb, est_priors=est_priors)
+            _tpull(c, params)
+            update_log_(logVar, params)
+            iters += done
+            i += done
+            if done < k:
+                break
+    else:
+        iters, d, _ = c.trial_run(int(niter), eps=eps, est_cb=est_cb, est_priors=est_priors)
+        _tpull(c, params)
+    params.YHat = params.BHat @ params.AHat.T if params.L * params.M <= YHAT_AUTO_LIMIT else None   # :590
+    if verb:
+        print(f"Factorization finished after {iters} iterations, eps = {d}")
+    if logdir != "":
+        save_log(logVar, Y, {}, logdir, desc=desc)
+    params._last_run = (iters, d)
+    return d
+
+
+def vbmf_trial(Y, params_in, niter, **kw):
+    """vbmf_trial -- src/vbmf_trial.jl:612-623: deep-copies params_in (:234-242), returns (params, d)."""
+    import copy as _copy
+    p = _copy.deepcopy(params_in)
+    d = vbmf_trial_(Y, p, niter, **kw)
+    return p, d
+
+
+def lowerBound_trial(Y, params, clamp=True):
+    """lowerBound(Y, ::vbmf_trial_parameters) -- src/vbmf_trial.jl:630-680."""
+    c = _sparse_ctx(Y, params, trial=True)
+    _tpush(c, params)
+    return c.sparse_lower_bound(clamp=clamp)
+
+
+# =================================================================================================
 # Fixed-basis inference -- examples/mil_util.jl:179-236 (vbls!, copy_vbmf_params): the main caller of the
 # update functions outside vbmf!/vbmf_sparse! (150 resp. 20 iterations per bag in the MIL study,
 # examples/mil_util.jl:473-479,518-521)
@@ -732,6 +957,15 @@ def vbls_(Y, params, niter, diag_var=False, full_cov=False):
         c.sparse_run_fixed_basis(int(niter))
         _dpull(c, params)
         _dpull_priors(c, params)
+        params.YHat = params.BHat @ params.AHat.T if params.L * params.M <= YHAT_AUTO_LIMIT else None
+        return params.AHat
+    if isinstance(params, vbmf_trial_parameters):                        # examples/mil_util.jl:194-197
+        if diag_var:
+            raise NotImplementedError("the three-group model is built for diag_var=false")
+        c = _sparse_ctx(Y, params, trial=True)
+        _tpush(c, params)
+        c.sparse_run_fixed_basis(int(niter))
+        _tpull(c, params)
         params.YHat = params.BHat @ params.AHat.T if params.L * params.M <= YHAT_AUTO_LIMIT else None
         return params.AHat
     if isinstance(params, vbmf_sparse_parameters):

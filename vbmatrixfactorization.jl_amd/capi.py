@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libvbmf_hip.so")
 
 VBMF_Y_F32, VBMF_Y_BF16 = 0, 1
 VBMF_FACTOR_AUTO, VBMF_FACTOR_BF16, VBMF_FACTOR_BF16X2 = 0, 1, 2
-VBMF_VARIANT_BASIC, VBMF_VARIANT_SPARSE_DIAG, VBMF_VARIANT_SPARSE_DIAGVAR, VBMF_VARIANT_DUAL_DIAG = 0, 1, 2, 3
+VBMF_VARIANT_BASIC, VBMF_VARIANT_SPARSE_DIAG, VBMF_VARIANT_SPARSE_DIAGVAR, VBMF_VARIANT_DUAL_DIAG, VBMF_VARIANT_TRIAL_DIAG = 0, 1, 2, 3, 4
 VBMF_COMPAT_SPECTRAL_DELTA, VBMF_COMPAT_SPARSE_REPEAT, VBMF_COMPAT_DEFAULT = 1, 2, 0xFFFFFFFF
 STEP_A, STEP_B, STEP_CA, STEP_CB, STEP_SIGMA2 = 1, 2, 4, 8, 16
 UNIQUE_ID_BYTES = 128
@@ -28,6 +28,7 @@ SYMBOLS = [
     "vbmf_sparse_set_state", "vbmf_sparse_get_state", "vbmf_sparse_step", "vbmf_sparse_run", "vbmf_sparse_run_fixed_basis",
     "vbmf_sparse_lower_bound", "vbmf_sparse_set_noise_rows", "vbmf_sparse_get_noise_rows", "vbmf_preprocess_open", "vbmf_preprocess_rows", "vbmf_set_Y_preprocessed",
     "vbmf_preprocess_close", "vbmf_dual_set_priors", "vbmf_dual_get_priors", "vbmf_dual_run",
+    "vbmf_trial_set_priors", "vbmf_trial_get_priors", "vbmf_trial_run",
 ]
 SSTEP_A, SSTEP_B, SSTEP_CA, SSTEP_CB, SSTEP_SIGMA, SSTEP_PRIORS = 1, 2, 4, 8, 16, 32
 PEEK_P, PEEK_Q, PEEK_A32, PEEK_B32, PEEK_FA, PEEK_FB, PEEK_Y1, PEEK_Y2, PEEK_DIMS = range(9)
@@ -115,6 +116,9 @@ def lib():
     L.vbmf_dual_set_priors.argtypes = [vp, i64] + [C.c_double] * 6
     L.vbmf_dual_get_priors.argtypes = [vp, C.POINTER(i64), dp]
     L.vbmf_dual_run.argtypes = [vp, i64, C.c_double, i32, i32, C.POINTER(i64), dp, dp]
+    L.vbmf_trial_set_priors.argtypes = [vp, i64, i64, dp]
+    L.vbmf_trial_get_priors.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), dp]
+    L.vbmf_trial_run.argtypes = [vp, i64, C.c_double, i32, i32, C.POINTER(i64), dp, dp]
     L.vbmf_sparse_set_noise_rows.argtypes = [vp, dp, dp, C.c_double]
     L.vbmf_sparse_get_noise_rows.argtypes = [vp, dp, dp]
     L.vbmf_preprocess_open.argtypes = [C.POINTER(vp), i32, dp, i64, i64, i64, C.POINTER(i64)]
@@ -358,6 +362,24 @@ class Context:
         it = C.c_int64(); d = C.c_double()
         tr = np.zeros((max(niter, 1), 4)) if want_trace else None
         self._chk(self._lib.vbmf_dual_run(self._h, niter, eps, int(est_cb), int(est_priors), C.byref(it), C.byref(d), _dptr(tr)))
+        return it.value, d.value, (tr[:it.value] if want_trace else None)
+
+    # ---- three-group ARD variant (variant=VBMF_VARIANT_TRIAL_DIAG) ----
+    TRIAL_KEYS = ("alpha01", "beta01", "alpha02", "beta02", "alpha03", "beta03", "alpha1", "alpha2", "alpha3")
+
+    def trial_set_priors(self, H0, M0, priors):
+        v = np.array([float(priors[k]) for k in self.TRIAL_KEYS])
+        self._chk(self._lib.vbmf_trial_set_priors(self._h, int(H0), int(M0), _dptr(v)))
+
+    def trial_get_priors(self):
+        h0, m0 = C.c_int64(), C.c_int64(); v = np.empty(9)
+        self._chk(self._lib.vbmf_trial_get_priors(self._h, C.byref(h0), C.byref(m0), _dptr(v)))
+        return h0.value, m0.value, {k: float(v[i]) for i, k in enumerate(self.TRIAL_KEYS)}
+
+    def trial_run(self, niter, eps=1e-6, est_cb=True, est_priors=True, want_trace=False):
+        it = C.c_int64(); d = C.c_double()
+        tr = np.zeros((max(niter, 1), 4)) if want_trace else None
+        self._chk(self._lib.vbmf_trial_run(self._h, niter, eps, int(est_cb), int(est_priors), C.byref(it), C.byref(d), _dptr(tr)))
         return it.value, d.value, (tr[:it.value] if want_trace else None)
 
     # ---- multi-GPU ----

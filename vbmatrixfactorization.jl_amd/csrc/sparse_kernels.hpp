@@ -9,7 +9,7 @@
 //   sparse_cov_b       SigmaB = inv(diag(CB) + sigmaHat (A'A + SigmaA))                    (:263-265)
 //   sparse_ctrl_end    CB/delta (:295-300), zeta/sigmaHat (:317-321), d and the loop test (:389,368)
 //   sparse_lb_sums     the M*H-long sums lowerBound needs                                  (:442-443,453-455,461,467)
-//   dual_priors        the two-group model's hyper-prior fits (src/vbmf_dual.jl:393-434)
+//   group_priors       the grouped models' hyper-prior fits (src/vbmf_dual.jl:393-434, src/vbmf_trial.jl:442-507)
 // State block reuse: S_SIGMA2 holds sigmaHat (a PRECISION here), the `ca` strip holds delta, `cb` holds CB.
 #pragma once
 #include "common.hpp"
@@ -63,51 +63,59 @@ __global__ __launch_bounds__(256) void sparse_update_a_kernel(const float* __res
     }
 }
 
-// Two-group model (src/vbmf_dual.jl:322-351): columns h < H0 use (alpha00, beta00), the rest (alpha01, beta01), read
-// from the state block (`grp` = scal, they change on the device every sweep under est_priors); the posterior
-// shapes are alpha0g + 1/2 (:324-325).  gpart != nullptr: per-block [sum log(beta), sum CA] of each group, what the
-// hyper-prior fits need (:393-434).
-// S_ALPHA0P / S_ALPHA1P: the posterior shapes alpha0 / alpha1 as the last updateCA! set them (what lowerBound reads, :564-565)
-enum : int { S_ALPHA00 = 21, S_BETA00 = 22, S_ALPHA01 = 23, S_BETA01 = 24, S_ALPHA0P = 25, S_ALPHA1P = 26 };
+// Grouped models (src/vbmf_dual.jl:322-351, src/vbmf_trial.jl:357-400): the entries of vec(A') fall into up to three
+// groups with their own Gamma hyper-prior -- g = 0: columns h < H0 (all rows); g = 1: h >= H0, rows m < M0; g = 2:
+// h >= H0, rows m >= M0 (vbmf_dual: M0 = M, two groups).  Priors (alpha0g, beta0g) at scal[S_GPRI + 2g, +1], read from
+// the state block (`grp` = scal: they change on the device every sweep under est_priors); the posterior shapes
+// alpha0g + 1/2 (:324-325 / :359-361) are recorded at scal[S_GPOST + g] (what lowerBound reads).
+// gpart != nullptr: per-block [sum log(beta), sum CA] of each group, what the hyper-prior fits need.
+enum : int { S_GPRI = 21, S_GPOST = 27 };
+__device__ __forceinline__ int ca_group(long long m, int h, int H0, long long M0) { return h < H0 ? 0 : (m < M0 ? 1 : 2); }
 __global__ __launch_bounds__(256) void sparse_update_ca_kernel(const float* __restrict__ A32,
                                                                const float* __restrict__ dS32,
                                                                float* __restrict__ beta32, float* __restrict__ CA32,
                                                                double alpha, double beta0, long long M, int H, int Hp,
                                                                const int* __restrict__ stop,
-                                                               double* __restrict__ grp, int H0,
+                                                               double* __restrict__ grp, int H0, long long M0,
                                                                double* __restrict__ gpart) {
-    __shared__ double sh[4][4];
+    __shared__ double sh[4][6];
     if (stop && *stop) return;
-    double al0 = alpha, al1 = alpha, b00 = beta0, b01 = beta0;
+    double al[3] = {alpha, alpha, alpha}, b0[3] = {beta0, beta0, beta0};
     if (grp) {
-        al0 = grp[S_ALPHA00] + 0.5; b00 = grp[S_BETA00]; al1 = grp[S_ALPHA01] + 0.5; b01 = grp[S_BETA01];
-        if (blockIdx.x == 0 && threadIdx.x == 0) { grp[S_ALPHA0P] = al0; grp[S_ALPHA1P] = al1; }      // :324-325
+#pragma unroll
+        for (int g = 0; g < 3; ++g) { al[g] = grp[S_GPRI + 2 * g] + 0.5; b0[g] = grp[S_GPRI + 2 * g + 1]; }
+        if (blockIdx.x == 0 && threadIdx.x == 0) { grp[S_GPOST] = al[0]; grp[S_GPOST + 1] = al[1]; grp[S_GPOST + 2] = al[2]; }
     }
-    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    double s[6] = {0, 0, 0, 0, 0, 0};
     const long long total = M * Hp;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
-        const int h = (int)(i % Hp);
+        const long long m = i / Hp;
+        const int h = (int)(i - m * Hp);
         if (h >= H) continue;
-        const bool g0 = h < H0;
+        const int g = ca_group(m, h, H0, M0);
         const double a = (double)A32[i];
-        const double b = (g0 ? b00 : b01) + 0.5 * (a * a + (double)dS32[i]);
-        const double ca = (g0 ? al0 : al1) / b;
+        const double b = (g == 0 ? b0[0] : (g == 1 ? b0[1] : b0[2])) + 0.5 * (a * a + (double)dS32[i]);
+        const double ca = (g == 0 ? al[0] : (g == 1 ? al[1] : al[2])) / b;
         beta32[i] = (float)b;
         CA32[i] = (float)ca;
         if (gpart) {
             const double lb = log(b);
-            if (g0) { s0 += lb; s1 += ca; } else { s2 += lb; s3 += ca; }
+            if (g == 0) { s[0] += lb; s[1] += ca; } else if (g == 1) { s[2] += lb; s[3] += ca; } else { s[4] += lb; s[5] += ca; }
         }
     }
     if (!gpart) return;
-    for (int off = 32; off > 0; off >>= 1) {
-        s0 += __shfl_down(s0, off); s1 += __shfl_down(s1, off); s2 += __shfl_down(s2, off); s3 += __shfl_down(s3, off);
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+        for (int off = 32; off > 0; off >>= 1) s[k] += __shfl_down(s[k], off);
+    if ((threadIdx.x & 63) == 0) {
+        const int w = threadIdx.x >> 6;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) sh[w][k] = s[k];
     }
-    if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; sh[w][0] = s0; sh[w][1] = s1; sh[w][2] = s2; sh[w][3] = s3; }
     __syncthreads();
-    if (threadIdx.x < 4)
-        gpart[(long long)blockIdx.x * 4 + threadIdx.x] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+    if (threadIdx.x < 6)
+        gpart[(long long)blockIdx.x * 6 + threadIdx.x] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
 }
 
 // digamma / trigamma in fp64: recurrence up to x >= 8, then the asymptotic series
@@ -138,29 +146,31 @@ __device__ inline double digamma_inv_dev(double y) {
     return x;
 }
 
-// est_priors (src/vbmf_dual.jl:491-495): alpha0g <- root of  n log(beta0g) - n digamma(x) + sum_i gammaELn(alpha_g, beta_i)
-// on [1e-10, 1e10] (:394-400; Roots.jl's fzero restated as the exact root, unchanged when the bracket holds no sign
-// change -- the reference's `try ... end`), then beta0g <- n alpha0g / sum(CA_g) (:408-410).  One block.
-__global__ __launch_bounds__(256) void dual_priors_kernel(const double* __restrict__ gpart, int nblocks,
-                                                          double* __restrict__ st, StateLayout lay, double M, int H, int H0,
-                                                          const int* __restrict__ stop) {
+// est_priors (src/vbmf_dual.jl:491-495, src/vbmf_trial.jl:565-572): alpha0g <- root of
+//   n_g log(beta0g) - n_g digamma(x) + sum_i gammaELn(alpha_g, beta_i)   on [1e-10, 1e10]
+// (dual :394-400; Roots.jl's fzero restated as the exact root, unchanged when the bracket holds no sign change -- the
+// reference's `try ... end`), then beta0g <- n_g alpha0g / sum(CA_g) (:408-410).  One block.
+__global__ __launch_bounds__(256) void group_priors_kernel(const double* __restrict__ gpart, int nblocks,
+                                                           double* __restrict__ st, StateLayout lay, double M, int H, int H0,
+                                                           double M0, const int* __restrict__ stop) {
     __shared__ double red[16];
-    __shared__ double tot[4];
+    __shared__ double tot[6];
     if (stop && *stop) return;
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < 6; ++k) {
         double s = 0.0;
-        for (int b = threadIdx.x; b < nblocks; b += blockDim.x) s += gpart[(long long)b * 4 + k];
+        for (int b = threadIdx.x; b < nblocks; b += blockDim.x) s += gpart[(long long)b * 6 + k];
         s = block_sum(s, red);
         if (threadIdx.x == 0) tot[k] = s;
         __syncthreads();
     }
     if (threadIdx.x != 0) return;
     double* scal = st + lay.scal();
-    for (int g = 0; g < 2; ++g) {
-        const double n = M * (double)(g == 0 ? H0 : H - H0);
+    const double ng[3] = {M * (double)H0, M0 * (double)(H - H0), (M - M0) * (double)(H - H0)};
+    for (int g = 0; g < 3; ++g) {
+        const double n = ng[g];
         if (!(n > 0.0)) continue;                                  // empty group: nothing to fit
-        const int ia = g == 0 ? S_ALPHA00 : S_ALPHA01, ib = g == 0 ? S_BETA00 : S_BETA01;
-        const double a_post = scal[g == 0 ? S_ALPHA0P : S_ALPHA1P];    // = alpha0g + 1/2, set by this sweep's updateCA!
+        const int ia = S_GPRI + 2 * g, ib = ia + 1;
+        const double a_post = scal[S_GPOST + g];                   // = alpha0g + 1/2, set by this sweep's updateCA!
         const double y = log(scal[ib]) + digamma_dev(a_post) - tot[2 * g] / n;
         double a_new = scal[ia];
         // f(1e-10) > 0 always (digamma(1e-10) ~ -1e10); the bracket has a sign change iff y < digamma(1e10)
@@ -368,33 +378,37 @@ __global__ __launch_bounds__(1024) void sparse_ctrl_end_kernel(double* __restric
     }
 }
 
-// partials[b][0..5] = [ sum log(beta) g0, sum log(beta) g1, sum CA*(A^2 + dS), sum CA g0, sum CA g1, sum log(dS) ] over
-// the valid M x H entries (g0: columns h < H0; the one-group sparse model passes H0 = H)
+// partials[b][0..7] = [ sum log(beta) g0, g1, g2, sum CA*(A^2 + dS), sum CA g0, g1, g2, sum log(dS) ] over the valid
+// M x H entries (groups as in sparse_update_ca_kernel; the one-group sparse model passes H0 = H)
 __global__ __launch_bounds__(256) void sparse_lb_sums_kernel(const float* __restrict__ A32, const float* __restrict__ dS32,
                                                              const float* __restrict__ CA32, const float* __restrict__ beta32,
-                                                             long long M, int H, int Hp, int H0, double* __restrict__ partials) {
-    __shared__ double sh[4][6];
-    double s[6] = {0, 0, 0, 0, 0, 0};
+                                                             long long M, int H, int Hp, int H0, long long M0,
+                                                             double* __restrict__ partials) {
+    __shared__ double sh[4][8];
+    double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const long long total = M * Hp;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
-        const int h = (int)(i % Hp);
+        const long long m = i / Hp;
+        const int h = (int)(i - m * Hp);
         if (h >= H) continue;
         const double a = A32[i], ds = dS32[i], ca = CA32[i], be = beta32[i];
-        if (h < H0) { s[0] += log(be); s[3] += ca; } else { s[1] += log(be); s[4] += ca; }
-        s[2] += ca * (a * a + ds); s[5] += log(ds);
+        const int g = ca_group(m, h, H0, M0);
+        const double lb = log(be);
+        if (g == 0) { s[0] += lb; s[4] += ca; } else if (g == 1) { s[1] += lb; s[5] += ca; } else { s[2] += lb; s[6] += ca; }
+        s[3] += ca * (a * a + ds); s[7] += log(ds);
     }
 #pragma unroll
-    for (int k = 0; k < 6; ++k)
+    for (int k = 0; k < 8; ++k)
         for (int off = 32; off > 0; off >>= 1) s[k] += __shfl_down(s[k], off);
     if ((threadIdx.x & 63) == 0) {
         const int w = threadIdx.x >> 6;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) sh[w][k] = s[k];
+        for (int k = 0; k < 8; ++k) sh[w][k] = s[k];
     }
     __syncthreads();
-    if (threadIdx.x < 6)
-        partials[(long long)blockIdx.x * 6 + threadIdx.x] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+    if (threadIdx.x < 8)
+        partials[(long long)blockIdx.x * 8 + threadIdx.x] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
 }
 
 // ---- heteroscedastic rows (diag_var = true, src/vbmf_sparse.jl:207-212, 229-230, 256-261, 308-315) ----------

@@ -73,8 +73,9 @@ struct vbmf_ctx {
     double etaVec = 0.0;
     double* vtab = nullptr;          // v[h] of src/vbmf_sparse.jl:217
     // two-group ARD variant (src/vbmf_dual.jl, diagonal branch): columns h < H0 / h >= H0 have their own hyper-priors
-    bool dual = false;
-    int64_t H0 = 0;
+    bool dual = false;               // grouped model: VBMF_VARIANT_DUAL_DIAG (two groups) or VBMF_VARIANT_TRIAL_DIAG (three)
+    bool trial = false;
+    int64_t H0 = 0, M0 = 0;          // group 0: columns h < H0; groups 1 / 2: the other columns of rows m < M0 / m >= M0
     double* gpart = nullptr;         // per-block [sum log beta, sum CA] x 2 groups
     int gpart_blocks = 0;
     vbmf_sparse_hyper hyp{};
@@ -809,13 +810,15 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
     if (L <= 0 || M <= 0 || H <= 0) { c->err = "L, M, H must be positive"; return bail(VBMF_ERR_INVALID); }
     if (H > 256) { c->err = "H > 256 is not supported"; return bail(VBMF_ERR_UNSUPPORTED); }
     if (c->o.variant != VBMF_VARIANT_BASIC && c->o.variant != VBMF_VARIANT_SPARSE_DIAG && c->o.variant != VBMF_VARIANT_SPARSE_DIAGVAR &&
-        c->o.variant != VBMF_VARIANT_DUAL_DIAG) {
+        c->o.variant != VBMF_VARIANT_DUAL_DIAG && c->o.variant != VBMF_VARIANT_TRIAL_DIAG) {
         c->err = "unknown variant"; return bail(VBMF_ERR_INVALID);
     }
     c->sparse = (c->o.variant != VBMF_VARIANT_BASIC);
     c->diagvar = (c->o.variant == VBMF_VARIANT_SPARSE_DIAGVAR);
-    c->dual = (c->o.variant == VBMF_VARIANT_DUAL_DIAG);
+    c->trial = (c->o.variant == VBMF_VARIANT_TRIAL_DIAG);
+    c->dual = (c->o.variant == VBMF_VARIANT_DUAL_DIAG) || c->trial;
     c->H0 = H;
+    c->M0 = M;
     if (c->o.nranks < 1 || c->o.rank < 0 || c->o.rank >= c->o.nranks) { c->err = "bad nranks/rank"; return bail(VBMF_ERR_INVALID); }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -909,7 +912,7 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
     }
     if (c->dual) {
         c->gpart_blocks = grid_for((int64_t)c->M * c->Hp);
-        ALLOC(c->gpart, (size_t)c->gpart_blocks * 4 * 8);
+        ALLOC(c->gpart, (size_t)c->gpart_blocks * 6 * 8);
     }
     if (c->diagvar) {
         ALLOC(c->sigv, (size_t)c->Lp * 8);
@@ -1732,14 +1735,15 @@ static int do_hetero_sigma(vbmf_ctx* c) {
 static int sparse_update_CA(vbmf_ctx* c) {
     hipLaunchKernelGGL(sparse_update_ca_kernel, dim3(grid_for((int64_t)c->M * c->Hp)), dim3(256), 0, c->stream, c->A32, c->dS32,
                        c->beta32, c->CA32, c->alpha, c->hyp.beta0, (long long)c->M, (int)c->H, c->Hp, c->ints + I_STOP,
-                       c->dual ? c->st + c->lay.scal() : (double*)nullptr, (int)c->H0, c->dual ? c->gpart : (double*)nullptr);
+                       c->dual ? c->st + c->lay.scal() : (double*)nullptr, (int)c->H0, (long long)c->M0,
+                       c->dual ? c->gpart : (double*)nullptr);
     HIPCHK(c, hipGetLastError());
     return VBMF_OK;
 }
 // est_priors of vbmf_dual! (src/vbmf_dual.jl:491-495); needs the group sums of the sweep's updateCA!
 static int dual_update_priors(vbmf_ctx* c) {
-    hipLaunchKernelGGL(dual_priors_kernel, dim3(1), dim3(256), 0, c->stream, c->gpart, c->gpart_blocks, c->st, c->lay,
-                       (double)c->M, (int)c->H, (int)c->H0, c->ints + I_STOP);
+    hipLaunchKernelGGL(group_priors_kernel, dim3(1), dim3(256), 0, c->stream, c->gpart, c->gpart_blocks, c->st, c->lay,
+                       (double)c->M, (int)c->H, (int)c->H0, (double)c->M0, c->ints + I_STOP);
     HIPCHK(c, hipGetLastError());
     return VBMF_OK;
 }
@@ -1787,7 +1791,7 @@ int vbmf_sparse_set_state(vbmf_ctx* c, const double* ATVecHat, const double* dia
         FAIL(c, VBMF_ERR_INVALID, "vbmf_sparse_set_state: null pointer");
     if (ldB < c->L) FAIL(c, VBMF_ERR_INVALID, "ldB < L");
     if (H1 < 0 || H1 > c->H || nlabels < 0 || (nlabels > 0 && !labels0)) FAIL(c, VBMF_ERR_INVALID, "bad H1/labels");
-    if (c->dual && nlabels > 0) FAIL(c, VBMF_ERR_INVALID, "the two-group model has no label mask (src/vbmf_dual.jl:282-284)");
+    if (c->dual && nlabels > 0) FAIL(c, VBMF_ERR_INVALID, "the grouped models have no label mask (src/vbmf_dual.jl:282-284)");
     if (!(sigmaHat > 0.0)) FAIL(c, VBMF_ERR_INVALID, "sigmaHat must be positive");
     for (int64_t h = 0; h < c->H; ++h) if (!(CB[h] > 0.0)) FAIL(c, VBMF_ERR_INVALID, "CB must be positive");
     HIPCHK(c, hipSetDevice(c->o.device));
@@ -1810,9 +1814,8 @@ int vbmf_sparse_set_state(vbmf_ctx* c, const double* ATVecHat, const double* dia
     sc[S_SIGMA2] = sigmaHat; sc[S_ZETA] = zeta; sc[S_ALPHA] = c->alpha; sc[S_GAMMA] = c->gamma_; sc[S_ETA] = c->eta;
     sc[S_BETA0] = hyper->beta0; sc[S_DELTA0] = hyper->delta0; sc[S_ZETA0] = hyper->zeta0;
     // two-group model: both groups start from (alpha0, beta0) and H0 = H until vbmf_dual_set_priors says otherwise
-    sc[S_ALPHA00] = sc[S_ALPHA01] = hyper->alpha0; sc[S_BETA00] = sc[S_BETA01] = hyper->beta0;
-    sc[S_ALPHA0P] = sc[S_ALPHA1P] = hyper->alpha0 + 0.5;
-    if (c->dual) c->H0 = c->H;
+    for (int g = 0; g < 3; ++g) { sc[S_GPRI + 2 * g] = hyper->alpha0; sc[S_GPRI + 2 * g + 1] = hyper->beta0; sc[S_GPOST + g] = hyper->alpha0 + 0.5; }
+    if (c->dual) { c->H0 = c->H; c->M0 = c->M; }
     HIPCHK(c, hipMemcpy(c->st + c->lay.scal(), sc, sizeof sc, hipMemcpyHostToDevice));
     std::vector<unsigned char> mk((size_t)c->Mp, 0);
     for (int64_t i = 0; i < nlabels; ++i) {
@@ -1999,37 +2002,72 @@ int vbmf_sparse_run(vbmf_ctx* c, int64_t niter, double eps, int est_cb, int64_t*
     return sparse_run_impl(c, niter, eps, est_cb, 0, iters_done, d_last, trace);
 }
 
-// ---- two-group ARD variant (src/vbmf_dual.jl, full_cov=false, diag_var=false) ---------------------------------
+// ---- grouped ARD variants (src/vbmf_dual.jl, src/vbmf_trial.jl; full_cov=false, diag_var=false) -------------------
+// priors9 = {alpha0 prior, beta0 prior} x 3 groups, then the 3 posterior shapes
+static int group_set_priors(vbmf_ctx* c, int64_t H0, int64_t M0, const double* v9) {
+    if (!c->haveState) FAIL(c, VBMF_ERR_INVALID, "call vbmf_sparse_set_state first");
+    if (H0 < 0 || H0 > c->H) FAIL(c, VBMF_ERR_INVALID, "H must be at least H0!");          // src/vbmf_dual.jl:126-128
+    if (M0 < 0 || M0 > c->M) FAIL(c, VBMF_ERR_INVALID, "M0 must lie in 0..M");
+    for (int i = 0; i < 9; ++i)
+        if (!(v9[i] > 0.0) || !std::isfinite(v9[i])) FAIL(c, VBMF_ERR_INVALID, "the Gamma hyper-priors must be positive");
+    HIPCHK(c, hipSetDevice(c->o.device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(c->st + c->lay.scal() + S_GPRI, v9, 9 * 8, hipMemcpyHostToDevice));
+    c->H0 = H0;
+    c->M0 = M0;
+    return VBMF_OK;
+}
+
 int vbmf_dual_set_priors(vbmf_ctx* c, int64_t H0, double alpha00, double beta00, double alpha01, double beta01,
                          double alpha0, double alpha1) {
     if (!c) return VBMF_ERR_INVALID;
-    if (!c->dual) FAIL(c, VBMF_ERR_INVALID, "not a two-group context (opts.variant = VBMF_VARIANT_DUAL_DIAG)");
-    if (!c->haveState) FAIL(c, VBMF_ERR_INVALID, "call vbmf_sparse_set_state first");
-    if (H0 < 0 || H0 > c->H) FAIL(c, VBMF_ERR_INVALID, "H must be at least H0!");          // src/vbmf_dual.jl:126-128
-    if (!(alpha00 > 0.0) || !(beta00 > 0.0) || !(alpha01 > 0.0) || !(beta01 > 0.0) || !(alpha0 > 0.0) || !(alpha1 > 0.0))
-        FAIL(c, VBMF_ERR_INVALID, "the Gamma hyper-priors must be positive");
-    HIPCHK(c, hipSetDevice(c->o.device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    const double v[6] = {alpha00, beta00, alpha01, beta01, alpha0, alpha1};
-    HIPCHK(c, hipMemcpy(c->st + c->lay.scal() + S_ALPHA00, v, sizeof v, hipMemcpyHostToDevice));
-    c->H0 = H0;
-    return VBMF_OK;
+    if (!c->dual || c->trial) FAIL(c, VBMF_ERR_INVALID, "not a two-group context (opts.variant = VBMF_VARIANT_DUAL_DIAG)");
+    const double v[9] = {alpha00, beta00, alpha01, beta01, alpha01, beta01, alpha0, alpha1, alpha1};   // third group: empty
+    return group_set_priors(c, H0, c->M, v);
 }
 
 int vbmf_dual_get_priors(vbmf_ctx* c, int64_t* H0, double* priors6) {
     if (!c) return VBMF_ERR_INVALID;
-    if (!c->dual || !c->haveState) FAIL(c, VBMF_ERR_INVALID, "no two-group state");
+    if (!c->dual || c->trial || !c->haveState) FAIL(c, VBMF_ERR_INVALID, "no two-group state");
     HIPCHK(c, hipSetDevice(c->o.device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (H0) *H0 = c->H0;
-    if (priors6) HIPCHK(c, hipMemcpy(priors6, c->st + c->lay.scal() + S_ALPHA00, 6 * 8, hipMemcpyDeviceToHost));
+    if (priors6) {
+        double v[9];
+        HIPCHK(c, hipMemcpy(v, c->st + c->lay.scal() + S_GPRI, sizeof v, hipMemcpyDeviceToHost));
+        priors6[0] = v[0]; priors6[1] = v[1]; priors6[2] = v[2]; priors6[3] = v[3]; priors6[4] = v[6]; priors6[5] = v[7];
+    }
     return VBMF_OK;
 }
 
 int vbmf_dual_run(vbmf_ctx* c, int64_t niter, double eps, int est_cb, int est_priors, int64_t* iters_done,
                   double* d_last, double* trace) {
     if (!c) return VBMF_ERR_INVALID;
-    if (!c->dual) FAIL(c, VBMF_ERR_INVALID, "not a two-group context (opts.variant = VBMF_VARIANT_DUAL_DIAG)");
+    if (!c->dual || c->trial) FAIL(c, VBMF_ERR_INVALID, "not a two-group context (opts.variant = VBMF_VARIANT_DUAL_DIAG)");
+    return sparse_run_impl(c, niter, eps, est_cb, est_priors ? 1 : 0, iters_done, d_last, trace);
+}
+
+int vbmf_trial_set_priors(vbmf_ctx* c, int64_t H0, int64_t M0, const double* priors9) {
+    if (!c || !priors9) return VBMF_ERR_INVALID;
+    if (!c->trial) FAIL(c, VBMF_ERR_INVALID, "not a three-group context (opts.variant = VBMF_VARIANT_TRIAL_DIAG)");
+    return group_set_priors(c, H0, M0, priors9);
+}
+
+int vbmf_trial_get_priors(vbmf_ctx* c, int64_t* H0, int64_t* M0, double* priors9) {
+    if (!c) return VBMF_ERR_INVALID;
+    if (!c->trial || !c->haveState) FAIL(c, VBMF_ERR_INVALID, "no three-group state");
+    HIPCHK(c, hipSetDevice(c->o.device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (H0) *H0 = c->H0;
+    if (M0) *M0 = c->M0;
+    if (priors9) HIPCHK(c, hipMemcpy(priors9, c->st + c->lay.scal() + S_GPRI, 9 * 8, hipMemcpyDeviceToHost));
+    return VBMF_OK;
+}
+
+int vbmf_trial_run(vbmf_ctx* c, int64_t niter, double eps, int est_cb, int est_priors, int64_t* iters_done,
+                   double* d_last, double* trace) {
+    if (!c) return VBMF_ERR_INVALID;
+    if (!c->trial) FAIL(c, VBMF_ERR_INVALID, "not a three-group context (opts.variant = VBMF_VARIANT_TRIAL_DIAG)");
     return sparse_run_impl(c, niter, eps, est_cb, est_priors ? 1 : 0, iters_done, d_last, trace);
 }
 
@@ -2076,18 +2114,18 @@ int vbmf_sparse_lower_bound(vbmf_ctx* c, int clamp, double* lb) {
     TRY(launch_sparse_ctrl_end(c, f, 0.0, nullptr));       // no updates: stores tr(B'YA) in S_TRYBA
     const int nb = 256;
     hipLaunchKernelGGL(sparse_lb_sums_kernel, dim3(nb), dim3(256), 0, c->stream, c->A32, c->dS32, c->CA32, c->beta32,
-                       (long long)c->M, (int)c->H, c->Hp, (int)(c->dual ? c->H0 : c->H), c->ypart);
+                       (long long)c->M, (int)c->H, c->Hp, (int)(c->dual ? c->H0 : c->H), (long long)(c->dual ? c->M0 : c->M), c->ypart);
     HIPCHK(c, hipGetLastError());
-    std::vector<double> part((size_t)nb * 6), buf((size_t)c->lay.total());
+    std::vector<double> part((size_t)nb * 8), buf((size_t)c->lay.total());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(part.data(), c->ypart, part.size() * 8, hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(buf.data(), c->st, buf.size() * 8, hipMemcpyDeviceToHost));
-    double s_logbeta_g[2] = {0, 0}, s_ca_g[2] = {0, 0}, s_caq = 0, s_logds = 0;
+    double s_logbeta_g[3] = {0, 0, 0}, s_ca_g[3] = {0, 0, 0}, s_caq = 0, s_logds = 0;
     for (int b = 0; b < nb; ++b) {
-        s_logbeta_g[0] += part[6 * b]; s_logbeta_g[1] += part[6 * b + 1]; s_caq += part[6 * b + 2];
-        s_ca_g[0] += part[6 * b + 3]; s_ca_g[1] += part[6 * b + 4]; s_logds += part[6 * b + 5];
+        for (int g = 0; g < 3; ++g) { s_logbeta_g[g] += part[8 * b + g]; s_ca_g[g] += part[8 * b + 4 + g]; }
+        s_caq += part[8 * b + 3]; s_logds += part[8 * b + 7];
     }
-    const double s_logbeta = s_logbeta_g[0] + s_logbeta_g[1];
+    const double s_logbeta = s_logbeta_g[0] + s_logbeta_g[1] + s_logbeta_g[2];
     const double* sc = buf.data() + c->lay.scal();
     const double L = (double)c->Lg, M = (double)c->M, H = (double)c->H, MH = M * H;
     const double LN2PI = std::log(2.0 * M_PI);
@@ -2105,17 +2143,19 @@ int vbmf_sparse_lower_bound(vbmf_ctx* c, int clamp, double* lb) {
     const vbmf_sparse_hyper& hp = c->hyp;
     const double eln_sig = digamma_host(c->eta) - std::log(zeta);
     double s_eln_ca = MH * digamma_host(c->alpha) - s_logbeta;
-    // two-group model (src/vbmf_dual.jl:556-599): shapes alpha0g + 1/2 and priors (alpha0g, beta0g) per column group
-    double n_g[2] = {MH, 0.0}, a_post[2] = {c->alpha, c->alpha}, a_pri[2] = {c->hyp.alpha0, c->hyp.alpha0}, b_pri[2] = {c->hyp.beta0, c->hyp.beta0};
-    double eln_g[2] = {s_eln_ca, 0.0};
+    // grouped models (src/vbmf_dual.jl:556-599, src/vbmf_trial.jl:630-680): posterior shapes and priors per group
+    double n_g[3] = {MH, 0.0, 0.0}, a_post[3] = {c->alpha, c->alpha, c->alpha}, a_pri[3], b_pri[3];
+    double eln_g[3] = {s_eln_ca, 0.0, 0.0};
+    for (int g = 0; g < 3; ++g) { a_pri[g] = c->hyp.alpha0; b_pri[g] = c->hyp.beta0; }
     if (c->dual) {
-        for (int g = 0; g < 2; ++g) {
-            n_g[g] = M * (double)(g == 0 ? c->H0 : c->H - c->H0);
-            a_pri[g] = sc[S_ALPHA00 + 2 * g]; b_pri[g] = sc[S_BETA00 + 2 * g];
-            a_post[g] = sc[S_ALPHA0P + g];
+        const double H1 = (double)(c->H - c->H0);
+        n_g[0] = M * (double)c->H0; n_g[1] = (double)c->M0 * H1; n_g[2] = (M - (double)c->M0) * H1;
+        for (int g = 0; g < 3; ++g) {
+            a_pri[g] = sc[S_GPRI + 2 * g]; b_pri[g] = sc[S_GPRI + 2 * g + 1];
+            a_post[g] = sc[S_GPOST + g];
             eln_g[g] = n_g[g] > 0 ? n_g[g] * digamma_host(a_post[g]) - s_logbeta_g[g] : 0.0;
         }
-        s_eln_ca = eln_g[0] + eln_g[1];
+        s_eln_ca = eln_g[0] + eln_g[1] + eln_g[2];
     }
     const double s_eln_cb = H * digamma_host(c->gamma_) - sumlogdelta;
     double Lb = 0.0;
@@ -2128,7 +2168,7 @@ int vbmf_sparse_lower_bound(vbmf_ctx* c, int clamp, double* lb) {
     Lb += -0.5 * cbq;                                                                      // :447
     Lb += hp.eta0 * std::log(hp.zeta0) - std::lgamma(hp.eta0);                             // :449
     Lb += (hp.eta0 - 1) * eln_sig - hp.zeta0 * sig;                                        // :450
-    for (int g = 0; g < 2; ++g) {                                                          // one group in the sparse model
+    for (int g = 0; g < 3; ++g) {                                                          // one group in the sparse model
         if (!(n_g[g] > 0)) continue;
         Lb += n_g[g] * (a_pri[g] * std::log(b_pri[g]) - std::lgamma(a_pri[g]));            // :452   (dual :575, 579)
         Lb += (a_pri[g] - 1) * eln_g[g];                                                   // :453   (dual :576, 580)
@@ -2142,7 +2182,7 @@ int vbmf_sparse_lower_bound(vbmf_ctx* c, int clamp, double* lb) {
     if (clamp) logdet_kron = std::max(logdet_kron, std::log(4.9406564584124654e-324));     // src/util.jl:118-122
     Lb += L * H / 2 + L * H / 2 * LN2PI + 0.5 * logdet_kron;                               // :463
     Lb += c->eta + std::log(zeta) + std::lgamma(c->eta) + (1 - c->eta) * digamma_host(c->eta);               // :465
-    for (int g = 0; g < 2; ++g)                                                                              // :467 (dual :594, 596)
+    for (int g = 0; g < 3; ++g)                                                                              // :467 (dual :594, 596)
         if (n_g[g] > 0) Lb += n_g[g] * (a_post[g] + std::lgamma(a_post[g]) + (1 - a_post[g]) * digamma_host(a_post[g])) + s_logbeta_g[g];
     Lb += H * (c->gamma_ + std::lgamma(c->gamma_) + (1 - c->gamma_) * digamma_host(c->gamma_)) + sumlogdelta; // :469
     *lb = Lb;
