@@ -52,6 +52,8 @@ typedef enum {
 #define VBMF_VARIANT_SPARSE_DIAGVAR 2 /* src/vbmf_sparse.jl, full_cov=false, diag_var=true: one noise precision per row */
 #define VBMF_VARIANT_DUAL_DIAG 3    /* src/vbmf_dual.jl, full_cov=false, diag_var=false: two column groups A = [A0 A1] */
 #define VBMF_VARIANT_TRIAL_DIAG 4   /* src/vbmf_trial.jl, full_cov=false, diag_var=false: three groups A = [A1 [A2; A3]] */
+#define VBMF_VARIANT_DUAL_DIAGVAR 5  /* src/vbmf_dual.jl, full_cov=false, diag_var=true (rows' noise as in VBMF_VARIANT_SPARSE_DIAGVAR) */
+#define VBMF_VARIANT_TRIAL_DIAGVAR 6 /* src/vbmf_trial.jl, full_cov=false, diag_var=true */
 
 /* reference_compat bits (default: all set = behave like the reference) */
 #define VBMF_COMPAT_SPECTRAL_DELTA 1u  /* d uses operator 2-norms (src/util.jl:27-29, Julia 0.5 norm) */
@@ -171,7 +173,8 @@ int vbmf_sparse_run(vbmf_ctx* ctx, int64_t niter, double eps, int est_cb, int64_
  * normalEntropy's det (src/util.jl:118-122) when clamp != 0 */
 int vbmf_sparse_lower_bound(vbmf_ctx* ctx, int clamp, double* lb);
 
-/* ---- Two-group ARD variant (opts.variant = VBMF_VARIANT_DUAL_DIAG; src/vbmf_dual.jl, diagonal branch) -----------------
+/* ---- Two-group ARD variant (opts.variant = VBMF_VARIANT_DUAL_DIAG, or VBMF_VARIANT_DUAL_DIAGVAR for diag_var = true with the
+ * rows' noise state of vbmf_sparse_set_noise_rows; src/vbmf_dual.jl, diagonal branch) -----------------
  * vbmf_dual_parameters (src/vbmf_dual.jl:59-112): A = [A0 A1], H = H0 + H1; the element-wise precisions of columns
  * h < H0 have the Gamma hyper-prior (alpha00, beta00), those of the other columns (alpha01, beta01); posterior shapes are
  * alpha0g + 1/2 (:324-325).  updateA!/updateB!/updateCB!/updateSigma! are the sparse model's bodies (no label mask), so the
@@ -190,7 +193,8 @@ int vbmf_dual_get_priors(vbmf_ctx* ctx, int64_t* H0, double* priors6);
 int vbmf_dual_run(vbmf_ctx* ctx, int64_t niter, double eps, int est_cb, int est_priors, int64_t* iters_done,
                   double* d_last, double* trace);
 
-/* ---- Three-group ARD variant (opts.variant = VBMF_VARIANT_TRIAL_DIAG; src/vbmf_trial.jl, diagonal branch) ---------------
+/* ---- Three-group ARD variant (opts.variant = VBMF_VARIANT_TRIAL_DIAG / VBMF_VARIANT_TRIAL_DIAGVAR; src/vbmf_trial.jl,
+ * diagonal branch) ---------------
  * vbmf_trial_parameters (src/vbmf_trial.jl:68-131): A = [A1 [A2; A3]] -- A1 the first H0 columns (all M rows), A2 / A3 the
  * other H1 columns of rows m < M0 / m >= M0; each block has its own Gamma hyper-prior (alpha0g, beta0g), g = 1, 2, 3
  * (:357-400).  Everything else is the two-group model's: state through vbmf_sparse_set_state / get_state, updates through

@@ -843,18 +843,18 @@ def trial_updatePriors(p):
         p.beta03 = n[2] * p.alpha03 / float(np.sum(p.CA3))
 
 
-def vbmf_trial_(Y, p, niter, eps=1e-6, est_cb=True, est_priors=True, reference_compat=True, trace=None):
-    """vbmf_trial! -- src/vbmf_trial.jl:528-604 (full_cov=false, diag_var=false).  Returns (d, iterations)."""
+def vbmf_trial_(Y, p, niter, eps=1e-6, est_cb=True, est_priors=True, reference_compat=True, trace=None, diag_var=False):
+    """vbmf_trial! -- src/vbmf_trial.jl:528-604 (full_cov=false).  Returns (d, iterations)."""
     old = p.BHat.copy()
     d = eps + 1.0
     i = 1
     while i <= niter and d > eps:
-        trial_updateA(Y, p, reference_compat=reference_compat)
-        sparse_updateB(Y, p)                                             # :327-341
+        trial_updateA(Y, p, reference_compat=reference_compat, diag_var=diag_var)
+        sparse_updateB(Y, p, diag_var=diag_var)                          # :327-341
         trial_updateCA(p)
         if est_cb:
             sparse_updateCB(p)                                           # :407-412
-        sparse_updateSigma(Y, p)                                         # :419-435
+        sparse_updateSigma(Y, p, diag_var=diag_var)                      # :419-435
         if est_priors:
             trial_updatePriors(p)
         d = delta(p.BHat, old)

@@ -196,3 +196,36 @@ def test_dual_argument_errors(pkg):
             c.dual_run(1)                                                  # not a two-group context
         with pytest.raises(pkg.VbmfError):
             c.sparse_step(pkg.capi.SSTEP_CA | pkg.capi.SSTEP_PRIORS)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x2"])
+def test_dual_heteroscedastic_run(pkg, mode):
+    """vbmf_dual! with diag_var = true (src/vbmf_dual.jl:245-249, 263-264, 294-299, 371-378: the sparse model's
+    heteroscedastic bodies) and the prior fits, 8 sweeps; then vbls! with diag_var."""
+    L, M, H, H0 = 600, 380, 6, 4
+    rng = np.random.default_rng(177)
+    Y, A, B = O.toy_matrix(L, M, H, 0.0, rng)
+    Y = (B * np.linspace(1.0, 2.5, H)) @ A.T + rng.uniform(0.02, 0.4, (L, 1)) * rng.standard_normal((L, M))
+    po = O.vbmf_dual_init(Y, H, H0, ca=1.0, cb=1.0, sigma=1.0, rng=np.random.default_rng(178), materialize_yhat=False)
+    ydt = pkg.VBMF_Y_F32 if mode == "f32" else pkg.VBMF_Y_BF16
+    with pkg.capi.Context(L, M, H, y_dtype=ydt) as c:
+        c.set_Y(Y)
+        Ys = np.ascontiguousarray(c.get_Y())
+    po.trYTY = float(np.sum(Ys * Ys))
+    pkg.set_defaults(y_dtype=ydt, factor_dtype=pkg.VBMF_FACTOR_AUTO)
+
+    def to_pkg(q):
+        p = _to_pkg(pkg, q)
+        p.sigmaVecHat, p.etaVec, p.zetaVec = q.sigmaVecHat.copy(), q.etaVec.copy(), q.zetaVec.copy()
+        return p
+    pg = to_pkg(po)
+    d_gpu = pkg.vbmf_dual_(Ys, pg, 8, eps=0.0, diag_var=True, est_priors=True)
+    d_ref, n = O.vbmf_dual_(Ys, po, 8, eps=0.0, diag_var=True, est_priors=True)
+    tol = 2e-3 if mode == "f32" else 5e-3
+    _cmp(f"diag_var run8 {mode}", pg, po, tol, FIELDS + ("sigmaVecHat", "zetaVec"), priors_tol=tol)
+    assert pg._last_run[0] == 8 and abs(d_gpu - d_ref) <= 2e-2 * d_ref + 2e-6
+    pg = to_pkg(po)
+    pkg.vbls_(Ys, pg, 4, diag_var=True)
+    for _ in range(4):                                                      # examples/mil_util.jl:190-193
+        O.dual_updateA(Ys, po, diag_var=True); O.dual_updateCA(po); O.sparse_updateSigma(Ys, po, diag_var=True)
+    _cmp(f"diag_var vbls4 {mode}", pg, po, tol, ("ATVecHat", "diagSigmaATVec", "SigmaA", "CA", "beta", "sigmaVecHat", "zetaVec"))

@@ -176,3 +176,23 @@ def test_trial_fixed_basis_edges_and_errors(pkg):
             c.dual_run(1)                                                  # a three-group context is not a two-group one
         c.trial_set_priors(2, 10, pri)
         assert c.trial_get_priors()[:2] == (2, 10)
+
+
+def test_trial_heteroscedastic_run(pkg):
+    """vbmf_trial! with diag_var = true (the sparse model's heteroscedastic bodies, src/vbmf_trial.jl:279-283, 297-298,
+    329-334, 420-427) and the prior fits, 8 sweeps."""
+    L, M, H, H0, M0 = 600, 380, 6, 4, 150
+    rng = np.random.default_rng(277)
+    Y, A, B = O.toy_matrix(L, M, H, 0.0, rng)
+    Y = (B * np.linspace(1.0, 2.5, H)) @ A.T + rng.uniform(0.02, 0.4, (L, 1)) * rng.standard_normal((L, M))
+    po = O.vbmf_trial_init(Y, H, H0, M0, ca=1.0, cb=1.0, sigma=1.0, rng=np.random.default_rng(278), materialize_yhat=False)
+    Yf = Y.astype(np.float32).astype(np.float64)
+    po.trYTY = float(np.sum(Yf * Yf))
+    pkg.set_defaults(y_dtype=pkg.VBMF_Y_F32, factor_dtype=pkg.VBMF_FACTOR_AUTO)
+    pg = _to_pkg(pkg, po)
+    pg.sigmaVecHat, pg.etaVec, pg.zetaVec = po.sigmaVecHat.copy(), po.etaVec.copy(), po.zetaVec.copy()
+    d_gpu = pkg.vbmf_trial_(Yf, pg, 8, eps=0.0, diag_var=True, est_priors=True)
+    d_ref, n = O.vbmf_trial_(Yf, po, 8, eps=0.0, diag_var=True, est_priors=True)
+    _cmp("diag_var run8 f32", pg, po, 2e-3, FIELDS + ("sigmaVecHat", "zetaVec"), priors_tol=2e-3)
+    assert pg._last_run[0] == 8 and abs(d_gpu - d_ref) <= 2e-2 * d_ref + 2e-6
+    assert np.corrcoef(np.log(pg.sigmaVecHat), np.log(po.sigmaVecHat))[0, 1] > 0.999

@@ -34,7 +34,7 @@ from . import capi, dist
 from .data_manip import create_log, update_log_, save_log, load_log, extract_params_
 from .capi import PreprocessPlan
 from .capi import (Context, VbmfError, VBMF_Y_F32, VBMF_Y_BF16, VBMF_FACTOR_AUTO, VBMF_FACTOR_BF16,
-                   VBMF_FACTOR_BF16X2, VBMF_VARIANT_SPARSE_DIAG, VBMF_VARIANT_SPARSE_DIAGVAR, VBMF_VARIANT_DUAL_DIAG, VBMF_VARIANT_TRIAL_DIAG, STEP_A, STEP_B, STEP_CA, STEP_CB, STEP_SIGMA2,
+                   VBMF_FACTOR_BF16X2, VBMF_VARIANT_SPARSE_DIAG, VBMF_VARIANT_SPARSE_DIAGVAR, VBMF_VARIANT_DUAL_DIAG, VBMF_VARIANT_TRIAL_DIAG, VBMF_VARIANT_DUAL_DIAGVAR, VBMF_VARIANT_TRIAL_DIAGVAR, STEP_A, STEP_B, STEP_CA, STEP_CB, STEP_SIGMA2,
                    SSTEP_A, SSTEP_B, SSTEP_CA, SSTEP_CB, SSTEP_SIGMA, SSTEP_PRIORS)
 
 __all__ = ["vbmf_parameters", "vbmf_init", "vbmf", "vbmf_", "copy", "updateA_", "updateB_", "updateCA_",
@@ -386,9 +386,12 @@ def _sparse_ctx(Y, p, diag_var=False, dual=False, trial=False):
         return ent[0]
     for k in list(_sparse_sessions):
         _sparse_sessions.pop(k)[0].close()
-    if (dual or trial) and diag_var:
-        raise NotImplementedError("the grouped models are built for diag_var=false only")
-    variant = VBMF_VARIANT_TRIAL_DIAG if trial else (VBMF_VARIANT_DUAL_DIAG if dual else (VBMF_VARIANT_SPARSE_DIAGVAR if diag_var else VBMF_VARIANT_SPARSE_DIAG))
+    if trial:
+        variant = VBMF_VARIANT_TRIAL_DIAGVAR if diag_var else VBMF_VARIANT_TRIAL_DIAG
+    elif dual:
+        variant = VBMF_VARIANT_DUAL_DIAGVAR if diag_var else VBMF_VARIANT_DUAL_DIAG
+    else:
+        variant = VBMF_VARIANT_SPARSE_DIAGVAR if diag_var else VBMF_VARIANT_SPARSE_DIAG
     c = Context(Y.shape[0], Y.shape[1], p.H, variant=variant, **_defaults)
     c.set_Y(Y)
     _sparse_sessions[key] = (c, weakref.ref(Y))
@@ -496,7 +499,7 @@ def lowerBound(Y, params, clamp=True):
 
 
 # =================================================================================================
-# Two-group ARD variant -- src/vbmf_dual.jl with full_cov=false, diag_var=false
+# Two-group ARD variant -- src/vbmf_dual.jl with full_cov=false (either noise model)
 # =================================================================================================
 @dataclass
 class vbmf_dual_parameters:
@@ -594,14 +597,18 @@ def vbmf_dual_init(Y, H, H0, ca=1.0, alpha0=1e-10, beta0=1e-10, cb=1.0, gamma0=1
     return p
 
 
-def _dpush(c, p):
+def _dpush(c, p, diag_var=False):
     hyper = dict(alpha0=p.alpha00, beta0=p.beta00, gamma0=p.gamma0, delta0=p.delta0, eta0=p.eta0, zeta0=p.zeta0)
     c.sparse_set_state(p.ATVecHat, p.diagSigmaATVec, p.CA, p.beta, p.BHat, p.SigmaB, p.CB, p.delta, p.sigmaHat, p.zeta, hyper)
     c.dual_set_priors(p.H0, p.alpha00, p.beta00, p.alpha01, p.beta01, p.alpha0, p.alpha1)
+    if diag_var:
+        c.sparse_set_noise_rows(p.sigmaVecHat, p.zetaVec, float(np.asarray(p.etaVec).reshape(-1)[0]))
 
 
-def _dpull(c, p):
+def _dpull(c, p, diag_var=False):
     s = c.sparse_get_state()
+    if diag_var:
+        p.sigmaVecHat, p.zetaVec = c.sparse_get_noise_rows()
     p.ATVecHat, p.diagSigmaATVec, p.CA, p.beta = s["ATVecHat"], s["diagSigmaATVec"], s["CA"], s["beta"]
     p.AHat = p.ATVecHat.reshape(p.M, p.H).copy()
     p.A0Hat, p.A1Hat = p.AHat[:, :p.H0].copy(), p.AHat[:, p.H0:].copy()
@@ -609,7 +616,8 @@ def _dpull(c, p):
     p.beta0, p.beta1 = _dual_split(p.beta, p.M, p.H, p.H0)
     p.SigmaA = np.diag(s["SigmaA_diag"])
     p.BHat, p.SigmaB, p.CB, p.delta = s["BHat"], s["SigmaB"], s["CB"], s["delta"]
-    p.sigmaHat, p.zeta = s["sigmaHat"], s["zeta"]
+    if not diag_var:
+        p.sigmaHat, p.zeta = s["sigmaHat"], s["zeta"]
     return s
 
 
@@ -621,26 +629,24 @@ def _dpull_priors(c, p):
     p.alpha = np.array([p.alpha0, p.alpha1])
 
 
-def _done(Y, p, which):
-    c = _sparse_ctx(Y, p, dual=True)
-    _dpush(c, p)
+def _done(Y, p, which, diag_var=False):
+    c = _sparse_ctx(Y, p, diag_var, dual=True)
+    _dpush(c, p, diag_var)
     c.sparse_step(which)
-    _dpull(c, p)
+    _dpull(c, p, diag_var)
     _dpull_priors(c, p)
 
 
 def dual_updateA_(Y, params, full_cov=False, diag_var=False):
-    """updateA! -- src/vbmf_dual.jl:216-285 (diagonal branch, homoscedastic)."""
-    if full_cov or diag_var:
-        raise NotImplementedError("the two-group model is built for full_cov=false, diag_var=false")
-    _done(Y, params, SSTEP_A)
+    """updateA! -- src/vbmf_dual.jl:216-285 (diagonal branch)."""
+    if full_cov:
+        raise NotImplementedError("only full_cov=false is built")
+    _done(Y, params, SSTEP_A, diag_var)
 
 
 def dual_updateB_(Y, params, diag_var=False):
     """updateB! -- src/vbmf_dual.jl:292-306."""
-    if diag_var:
-        raise NotImplementedError("the two-group model is built for diag_var=false")
-    _done(Y, params, SSTEP_B)
+    _done(Y, params, SSTEP_B, diag_var)
 
 
 def dual_updateCA_(params, Y=None):
@@ -654,10 +660,8 @@ def dual_updateCB_(params, Y=None):
 
 
 def dual_updateSigma_(Y, params, diag_var=False):
-    """updateSigma! -- src/vbmf_dual.jl:370-386 (homoscedastic)."""
-    if diag_var:
-        raise NotImplementedError("the two-group model is built for diag_var=false")
-    _done(Y, params, SSTEP_SIGMA)
+    """updateSigma! -- src/vbmf_dual.jl:370-386 (diag_var: one Gamma posterior per row, :371-378)."""
+    _done(Y, params, SSTEP_SIGMA, diag_var)
 
 
 def dual_updateCA_and_priors_(params, Y=None):
@@ -669,10 +673,10 @@ def dual_updateCA_and_priors_(params, Y=None):
 def vbmf_dual_(Y, params, niter, eps=1e-6, diag_var=False, full_cov=False, logdir="", desc="", verb=False, est_priors=True,
                est_cb=True, log_every=1):
     """vbmf_dual! -- src/vbmf_dual.jl:455-530.  Returns d (like the reference).  logdir: see vbmf_."""
-    if full_cov or diag_var:
-        raise NotImplementedError("the two-group model is built for full_cov=false, diag_var=false")
-    c = _sparse_ctx(Y, params, dual=True)
-    _dpush(c, params)
+    if full_cov:
+        raise NotImplementedError("only full_cov=false is built")
+    c = _sparse_ctx(Y, params, diag_var, dual=True)
+    _dpush(c, params, diag_var)
     iters, d = 0, eps + 1.0
     if logdir != "":
         logVar = create_log(params)
@@ -680,7 +684,7 @@ def vbmf_dual_(Y, params, niter, eps=1e-6, diag_var=False, full_cov=False, logdi
         while i <= niter and d > eps:
             k = int(min(max(1, log_every), niter - i + 1))
             done, d, _ = c.dual_run(k, eps=eps, est_cb=est_cb, est_priors=est_priors)
-            _dpull(c, params)
+            _dpull(c, params, diag_var)
             _dpull_priors(c, params)
             update_log_(logVar, params)
             iters += done
@@ -689,7 +693,7 @@ def vbmf_dual_(Y, params, niter, eps=1e-6, diag_var=False, full_cov=False, logdi
                 break
     else:
         iters, d, _ = c.dual_run(int(niter), eps=eps, est_cb=est_cb, est_priors=est_priors)
-        _dpull(c, params)
+        _dpull(c, params, diag_var)
         _dpull_priors(c, params)
     params.YHat = params.BHat @ params.AHat.T if params.L * params.M <= YHAT_AUTO_LIMIT else None   # :516
     if verb:
@@ -716,7 +720,7 @@ def lowerBound_dual(Y, params, clamp=True):
 
 
 # =================================================================================================
-# Three-group ARD variant -- src/vbmf_trial.jl with full_cov=false, diag_var=false
+# Three-group ARD variant -- src/vbmf_trial.jl with full_cov=false (either noise model)
 # =================================================================================================
 @dataclass
 class vbmf_trial_parameters:
@@ -826,14 +830,18 @@ def vbmf_trial_init(Y, H, H0, M0, ca=1.0, alpha0=1e-10, beta0=1e-10, cb=1.0, gam
     return p
 
 
-def _tpush(c, p):
+def _tpush(c, p, diag_var=False):
     hyper = dict(alpha0=p.alpha01, beta0=p.beta01, gamma0=p.gamma0, delta0=p.delta0, eta0=p.eta0, zeta0=p.zeta0)
     c.sparse_set_state(p.ATVecHat, p.diagSigmaATVec, p.CA, p.beta, p.BHat, p.SigmaB, p.CB, p.delta, p.sigmaHat, p.zeta, hyper)
     c.trial_set_priors(p.H0, p.M0, {k: getattr(p, k) for k in Context.TRIAL_KEYS})
+    if diag_var:
+        c.sparse_set_noise_rows(p.sigmaVecHat, p.zetaVec, float(np.asarray(p.etaVec).reshape(-1)[0]))
 
 
-def _tpull(c, p):
+def _tpull(c, p, diag_var=False):
     s = c.sparse_get_state()
+    if diag_var:
+        p.sigmaVecHat, p.zetaVec = c.sparse_get_noise_rows()
     p.ATVecHat, p.diagSigmaATVec, p.CA, p.beta = s["ATVecHat"], s["diagSigmaATVec"], s["CA"], s["beta"]
     p.AHat = p.ATVecHat.reshape(p.M, p.H).copy()
     p.A1Hat, p.A2Hat, p.A3Hat = p.AHat[:, :p.H0].copy(), p.AHat[:p.M0, p.H0:].copy(), p.AHat[p.M0:, p.H0:].copy()
@@ -841,32 +849,31 @@ def _tpull(c, p):
     p.beta1, p.beta2, p.beta3 = _trial_split(p.beta, p.M, p.H, p.H0, p.M0)
     p.SigmaA = np.diag(s["SigmaA_diag"])
     p.BHat, p.SigmaB, p.CB, p.delta = s["BHat"], s["SigmaB"], s["CB"], s["delta"]
-    p.sigmaHat, p.zeta = s["sigmaHat"], s["zeta"]
+    if not diag_var:
+        p.sigmaHat, p.zeta = s["sigmaHat"], s["zeta"]
     _, _, pr = c.trial_get_priors()
     for k, v in pr.items():
         setattr(p, k, v)
     p.alpha = np.array([p.alpha1, p.alpha2, p.alpha3])
 
 
-def _tone(Y, p, which):
-    c = _sparse_ctx(Y, p, trial=True)
-    _tpush(c, p)
+def _tone(Y, p, which, diag_var=False):
+    c = _sparse_ctx(Y, p, diag_var, trial=True)
+    _tpush(c, p, diag_var)
     c.sparse_step(which)
-    _tpull(c, p)
+    _tpull(c, p, diag_var)
 
 
 def trial_updateA_(Y, params, full_cov=False, diag_var=False):
-    """updateA! -- src/vbmf_trial.jl:250-320 (diagonal branch, homoscedastic)."""
-    if full_cov or diag_var:
-        raise NotImplementedError("the three-group model is built for full_cov=false, diag_var=false")
-    _tone(Y, params, SSTEP_A)
+    """updateA! -- src/vbmf_trial.jl:250-320 (diagonal branch)."""
+    if full_cov:
+        raise NotImplementedError("only full_cov=false is built")
+    _tone(Y, params, SSTEP_A, diag_var)
 
 
 def trial_updateB_(Y, params, diag_var=False):
     """updateB! -- src/vbmf_trial.jl:327-341."""
-    if diag_var:
-        raise NotImplementedError("the three-group model is built for diag_var=false")
-    _tone(Y, params, SSTEP_B)
+    _tone(Y, params, SSTEP_B, diag_var)
 
 
 def trial_updateCA_(params, Y=None):
@@ -880,10 +887,8 @@ def trial_updateCB_(params, Y=None):
 
 
 def trial_updateSigma_(Y, params, diag_var=False):
-    """updateSigma! -- src/vbmf_trial.jl:419-435 (homoscedastic)."""
-    if diag_var:
-        raise NotImplementedError("the three-group model is built for diag_var=false")
-    _tone(Y, params, SSTEP_SIGMA)
+    """updateSigma! -- src/vbmf_trial.jl:419-435."""
+    _tone(Y, params, SSTEP_SIGMA, diag_var)
 
 
 def trial_updateCA_and_priors_(params, Y=None):
@@ -894,10 +899,10 @@ def trial_updateCA_and_priors_(params, Y=None):
 def vbmf_trial_(Y, params, niter, eps=1e-6, diag_var=False, full_cov=False, logdir="", desc="", verb=False, est_priors=True,
                 est_cb=True, log_every=1):
     """vbmf_trial! -- src/vbmf_trial.jl:528-604.  Returns d (like the reference).  logdir: see vbmf_."""
-    if full_cov or diag_var:
-        raise NotImplementedError("the three-group model is built for full_cov=false, diag_var=false")
-    c = _sparse_ctx(Y, params, trial=True)
-    _tpush(c, params)
+    if full_cov:
+        raise NotImplementedError("only full_cov=false is built")
+    c = _sparse_ctx(Y, params, diag_var, trial=True)
+    _tpush(c, params, diag_var)
     iters, d = 0, eps + 1.0
     if logdir != "":
         logVar = create_log(params)
@@ -905,7 +910,7 @@ def vbmf_trial_(Y, params, niter, eps=1e-6, diag_var=False, full_cov=False, logd
         while i <= niter and d > eps:
             k = int(min(max(1, log_every), niter - i + 1))
             done, d, _ = c.trial_run(k, eps=eps, est_cb=est_cb, est_priors=est_priors)
-            _tpull(c, params)
+            _tpull(c, params, diag_var)
             update_log_(logVar, params)
             iters += done
             i += done
@@ -913,7 +918,7 @@ def vbmf_trial_(Y, params, niter, eps=1e-6, diag_var=False, full_cov=False, logd
                 break
     else:
         iters, d, _ = c.trial_run(int(niter), eps=eps, est_cb=est_cb, est_priors=est_priors)
-        _tpull(c, params)
+        _tpull(c, params, diag_var)
     params.YHat = params.BHat @ params.AHat.T if params.L * params.M <= YHAT_AUTO_LIMIT else None   # :590
     if verb:
         print(f"Factorization finished after {iters} iterations, eps = {d}")
@@ -950,22 +955,18 @@ def vbls_(Y, params, niter, diag_var=False, full_cov=False):
     if full_cov:
         raise NotImplementedError("only full_cov=false is built (SURVEY.md section 2)")
     if isinstance(params, vbmf_dual_parameters):                         # examples/mil_util.jl:190-193
-        if diag_var:
-            raise NotImplementedError("the two-group model is built for diag_var=false")
-        c = _sparse_ctx(Y, params, dual=True)
-        _dpush(c, params)
+        c = _sparse_ctx(Y, params, diag_var, dual=True)
+        _dpush(c, params, diag_var)
         c.sparse_run_fixed_basis(int(niter))
-        _dpull(c, params)
+        _dpull(c, params, diag_var)
         _dpull_priors(c, params)
         params.YHat = params.BHat @ params.AHat.T if params.L * params.M <= YHAT_AUTO_LIMIT else None
         return params.AHat
     if isinstance(params, vbmf_trial_parameters):                        # examples/mil_util.jl:194-197
-        if diag_var:
-            raise NotImplementedError("the three-group model is built for diag_var=false")
-        c = _sparse_ctx(Y, params, trial=True)
-        _tpush(c, params)
+        c = _sparse_ctx(Y, params, diag_var, trial=True)
+        _tpush(c, params, diag_var)
         c.sparse_run_fixed_basis(int(niter))
-        _tpull(c, params)
+        _tpull(c, params, diag_var)
         params.YHat = params.BHat @ params.AHat.T if params.L * params.M <= YHAT_AUTO_LIMIT else None
         return params.AHat
     if isinstance(params, vbmf_sparse_parameters):

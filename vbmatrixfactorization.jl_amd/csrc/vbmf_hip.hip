@@ -810,13 +810,15 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
     if (L <= 0 || M <= 0 || H <= 0) { c->err = "L, M, H must be positive"; return bail(VBMF_ERR_INVALID); }
     if (H > 256) { c->err = "H > 256 is not supported"; return bail(VBMF_ERR_UNSUPPORTED); }
     if (c->o.variant != VBMF_VARIANT_BASIC && c->o.variant != VBMF_VARIANT_SPARSE_DIAG && c->o.variant != VBMF_VARIANT_SPARSE_DIAGVAR &&
-        c->o.variant != VBMF_VARIANT_DUAL_DIAG && c->o.variant != VBMF_VARIANT_TRIAL_DIAG) {
+        c->o.variant != VBMF_VARIANT_DUAL_DIAG && c->o.variant != VBMF_VARIANT_TRIAL_DIAG &&
+        c->o.variant != VBMF_VARIANT_DUAL_DIAGVAR && c->o.variant != VBMF_VARIANT_TRIAL_DIAGVAR) {
         c->err = "unknown variant"; return bail(VBMF_ERR_INVALID);
     }
     c->sparse = (c->o.variant != VBMF_VARIANT_BASIC);
-    c->diagvar = (c->o.variant == VBMF_VARIANT_SPARSE_DIAGVAR);
-    c->trial = (c->o.variant == VBMF_VARIANT_TRIAL_DIAG);
-    c->dual = (c->o.variant == VBMF_VARIANT_DUAL_DIAG) || c->trial;
+    c->diagvar = (c->o.variant == VBMF_VARIANT_SPARSE_DIAGVAR || c->o.variant == VBMF_VARIANT_DUAL_DIAGVAR ||
+                  c->o.variant == VBMF_VARIANT_TRIAL_DIAGVAR);
+    c->trial = (c->o.variant == VBMF_VARIANT_TRIAL_DIAG || c->o.variant == VBMF_VARIANT_TRIAL_DIAGVAR);
+    c->dual = (c->o.variant == VBMF_VARIANT_DUAL_DIAG || c->o.variant == VBMF_VARIANT_DUAL_DIAGVAR) || c->trial;
     c->H0 = H;
     c->M0 = M;
     if (c->o.nranks < 1 || c->o.rank < 0 || c->o.rank >= c->o.nranks) { c->err = "bad nranks/rank"; return bail(VBMF_ERR_INVALID); }
