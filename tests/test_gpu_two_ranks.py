@@ -53,8 +53,8 @@ def _check(pkg, world, transport, tmp_path, case="h12"):
     L, M, H = W.CASES[case]
     Y, A0, B0 = W.problem(L, M, H, W.SEED)
     with pkg.capi.Context(L, M, H, y_dtype=pkg.VBMF_Y_BF16, variant=W.variant_of(pkg, case)) as c:
-        if case in ("sparse", "hetero"):
-            ref = W.run_sparse(pkg, c, Y, A0, B0, H, W.NITERS[case], case == "hetero", L, 0)
+        if case in ("sparse", "hetero", "trial"):
+            ref = W.run_sparse(pkg, c, Y, A0, B0, H, W.NITERS[case], case == "hetero", L, 0, case == "trial")
         else:
             ref = W.run(pkg, c, Y, A0, B0, H, W.NITERS[case])
     ranks = _spawn(world, transport, tmp_path, case)
@@ -82,7 +82,12 @@ def _check(pkg, world, transport, tmp_path, case="h12"):
     # with it, so those see the fp32 reordering noise amplified; d is a difference of fp32-stored factors.
     # The sparse model's element-wise ARD (CA = alpha/beta with beta ~ A^2 + diagSigma, entries pruned over many orders
     # of magnitude) amplifies that reordering noise further: scalars (sigma, d, the bound) still agree to 1e-6.
-    k = 50.0 if case in ("sparse", "hetero") else 1.0
+    k = 50.0 if case in ("sparse", "hetero", "trial") else 1.0
+    if case == "trial":                                      # the fitted hyper-priors are replicated like the rest
+        for r in ranks[1:]:
+            assert np.array_equal(ranks[0]["priors"], r["priors"])
+        assert np.max(np.abs(ranks[0]["priors"] - ref["priors"]) / np.abs(ref["priors"])) < 1e-3
+        assert len(set(np.round(ranks[0]["priors"][[0, 2, 4]], 12))) == 3
     assert max(errs[k_] for k_ in ("A", "B", "ca", "cb")) < 2e-5 * k, errs
     assert max(errs[k_] for k_ in ("SA", "SB", "s2")) < 5e-4 * (2.0 if k > 1 else 1.0), errs
     assert errs["trYY"] < 1e-12 and errs["elbo"] < 1e-4, errs
@@ -102,10 +107,11 @@ def test_two_ranks_large_rank_paths(pkg, tmp_path, case):
     _check(pkg, 2, "host", tmp_path, case)
 
 
-@pytest.mark.parametrize("case", ["sparse", "hetero"])
+@pytest.mark.parametrize("case", ["sparse", "hetero", "trial"])
 def test_two_ranks_sparse_variant(pkg, tmp_path, case):
     """vbmf_sparse! row-sharded (homoscedastic, and one noise precision per row): Y'B, the Grams, ||Y||^2, and in the
-    heteroscedastic model sum_l (sigma_l B_lh)^2 and mean(sigma) are summed over the ranks."""
+    heteroscedastic model sum_l (sigma_l B_lh)^2 and mean(sigma) are summed over the ranks.  "trial": vbmf_trial! with its
+    hyper-prior fits, whose inputs (M x H sums) are replicated -- no further collective."""
     _check(pkg, 2, "host", tmp_path, case)
 
 

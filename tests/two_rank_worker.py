@@ -25,18 +25,21 @@ def problem(L, M, H, seed):
 # name -> (L, M, H): L deliberately not a multiple of the rank count.  "h128" runs the H = 128 kernels of the
 # 8-GPU BASELINE configuration (16 accumulator tiles per wave, un-fused post/Gram), "h200" the H > 128 control path.
 # "sparse" / "hetero": the ARD-sparse variant (homoscedastic / one noise precision per row) row-sharded.
+# "trial": the three-group variant with its hyper-prior fits (replicated M x H work: no further collective).
 CASES = {"h12": (1531, 700, 12), "h128": (1203, 520, 128), "h200": (901, 420, 200), "sparse": (1101, 480, 6),
-         "hetero": (1101, 480, 6)}
+         "hetero": (1101, 480, 6), "trial": (1101, 480, 6)}
+TRIAL_H0, TRIAL_M0 = 4, 190
 EPS, SEED = 0.0, 4242
-NITERS = {"h12": 12, "h128": 5, "h200": 5, "sparse": 8, "hetero": 8}
+NITERS = {"h12": 12, "h128": 5, "h200": 5, "sparse": 8, "hetero": 8, "trial": 8}
 HYPER = dict(alpha0=1e-10, beta0=1e-10, gamma0=1e-10, delta0=1e-10, eta0=1e-10, zeta0=1e-10)
 
 
 def variant_of(pkg, case):
-    return {"sparse": pkg.capi.VBMF_VARIANT_SPARSE_DIAG, "hetero": pkg.capi.VBMF_VARIANT_SPARSE_DIAGVAR}.get(case, pkg.capi.VBMF_VARIANT_BASIC)
+    return {"sparse": pkg.capi.VBMF_VARIANT_SPARSE_DIAG, "hetero": pkg.capi.VBMF_VARIANT_SPARSE_DIAGVAR,
+            "trial": pkg.capi.VBMF_VARIANT_TRIAL_DIAG}.get(case, pkg.capi.VBMF_VARIANT_BASIC)
 
 
-def run_sparse(pkg, ctx, Y, A0, B0, H, niter, hetero, L_global, row0):
+def run_sparse(pkg, ctx, Y, A0, B0, H, niter, hetero, L_global, row0, trial=False):
     """vbmf_sparse_init's initial state (src/vbmf_sparse.jl:101-153, ca = cb = sigma = 1) on this rank's rows."""
     M = A0.shape[0]
     n = Y.shape[0]
@@ -45,13 +48,20 @@ def run_sparse(pkg, ctx, Y, A0, B0, H, niter, hetero, L_global, row0):
                          np.ones(H), 1e-10 * np.ones(H), 1.0, 1e-10, HYPER)
     if hetero:
         ctx.sparse_set_noise_rows(np.ones(n), 1e-10 * np.ones(n), 1e-10 + M / 2)
-    it, d, _ = ctx.sparse_run(niter, eps=EPS, est_cb=True)
+    if trial:
+        pri = {k: (1e-10 + 0.5 if k in ("alpha1", "alpha2", "alpha3") else 1e-10) for k in pkg.capi.Context.TRIAL_KEYS}
+        ctx.trial_set_priors(TRIAL_H0, TRIAL_M0, pri)
+        it, d, _ = ctx.trial_run(niter, eps=EPS, est_cb=True, est_priors=True)
+    else:
+        it, d, _ = ctx.sparse_run(niter, eps=EPS, est_cb=True)
     s = ctx.sparse_get_state()
     out = dict(it=it, d=d, trYY=ctx.trYY(), AHat=s["ATVecHat"].reshape(M, H), BHat=s["BHat"], SigmaA=np.diag(s["SigmaA_diag"]),
                SigmaB=s["SigmaB"], CA_diag=s["CA"], CB_diag=s["CB"], sigma2=s["sigmaHat"], trace=np.zeros(1),
                elbo=0.0 if hetero else ctx.sparse_lower_bound())
     if hetero:
         out["sigmaVecHat"], out["zetaVec"] = ctx.sparse_get_noise_rows()
+    if trial:
+        out["priors"] = np.array(list(ctx.trial_get_priors()[2].values()))
     return out
 
 
@@ -86,8 +96,8 @@ def main():
             ctx.comm_init(uid[0])
         else:
             ctx.comm_set_transport(pkg.dist.host_staged_transport(lambda a: dist.all_reduce(torch.from_numpy(a))))
-        if case in ("sparse", "hetero"):
-            res = run_sparse(pkg, ctx, Y[r0:r0 + n], A0, B0[r0:r0 + n], H, NITERS[case], case == "hetero", L, r0)
+        if case in ("sparse", "hetero", "trial"):
+            res = run_sparse(pkg, ctx, Y[r0:r0 + n], A0, B0[r0:r0 + n], H, NITERS[case], case == "hetero", L, r0, case == "trial")
         else:
             res = run(pkg, ctx, Y[r0:r0 + n], A0, B0[r0:r0 + n], H, NITERS[case])
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), row0=r0, nrows=n, **res)
