@@ -172,6 +172,16 @@ int vbmf_sparse_run(vbmf_ctx* ctx, int64_t niter, double eps, int est_cb, int64_
 /* lowerBound (src/vbmf_sparse.jl:435-471), verbatim quirks QS4; H(B) as L*logdet(SigmaB), clamped like
  * normalEntropy's det (src/util.jl:118-122) when clamp != 0 */
 int vbmf_sparse_lower_bound(vbmf_ctx* ctx, int clamp, double* lb);
+/* full_cov = true of updateA! (src/vbmf_sparse.jl:178-202; dual :218-243; trial :252-277).  The reference's dense MH x MH
+ * invSigmaATVec = sigmaHat*kron(I_M, B'B + L*SigmaB) + diag(CA) is block diagonal, so the device inverts the M H x H blocks
+ * (one workgroup per column of Y) and never forms it: diagSigmaATVec = the blocks' diagonals, SigmaA = their sum (a full
+ * H x H matrix).  Applies to VBMF_SSTEP_A, the run loops and run_fixed_basis from then on.  Homoscedastic variants, H <= 64.
+ * The dense SigmaATVec / invSigmaATVec fields are not materialised. */
+int vbmf_sparse_set_full_cov(vbmf_ctx* ctx, int on);
+/* SigmaA as a full H x H matrix, column-major (vbmf_sparse_set_state derives a diagonal one from diagSigmaATVec; set it
+ * explicitly to continue a full_cov state) */
+int vbmf_sparse_set_SigmaA(vbmf_ctx* ctx, const double* SigmaA);
+int vbmf_sparse_get_SigmaA(vbmf_ctx* ctx, double* SigmaA);
 
 /* ---- Two-group ARD variant (opts.variant = VBMF_VARIANT_DUAL_DIAG, or VBMF_VARIANT_DUAL_DIAGVAR for diag_var = true with the
  * rows' noise state of vbmf_sparse_set_noise_rows; src/vbmf_dual.jl, diagonal branch) -----------------

@@ -216,3 +216,101 @@ def test_hetero_run(pkg, mode):
     errs = {f: relF(getattr(qg, f), getattr(qo, f)) for f in ("ATVecHat", "diagSigmaATVec", "CA", "sigmaVecHat")}
     report(f"sparse diag_var vbls5 {mode}: " + " ".join(f"{k}={v:.2e}" for k, v in errs.items()))
     assert max(errs.values()) < (2e-3 if mode == "f32" else 5e-3), errs
+
+
+# ---- full_cov = true (src/vbmf_sparse.jl:178-202): the branch the reference's recorded sparse run used ------------------
+def _fixture_params(pkg, g, t):
+    p = pkg.vbmf_sparse_parameters()
+    p.L, p.M, p.H, p.H1 = int(g["L"][t]), int(g["M"][t]), int(g["H"][t]), int(g["H1"][t])
+    p.MH = p.M * p.H
+    for f in ("AHat", "ATVecHat", "diagSigmaATVec", "SigmaA", "BHat", "SigmaB", "CA", "beta", "CB", "delta"):
+        setattr(p, f, g[f][t].copy())
+    for f in ("alpha0", "beta0", "alpha", "gamma0", "delta0", "gamma", "sigmaHat", "eta0", "zeta0", "eta", "zeta", "trYTY"):
+        setattr(p, f, float(g[f][t]))
+    return p
+
+
+RFIELDS = ("AHat", "ATVecHat", "diagSigmaATVec", "SigmaA", "BHat", "SigmaB", "CA", "beta", "CB", "delta")
+
+
+def test_full_cov_each_update_against_the_reference_record(pkg, golden_dir):
+    """PINNED: every recorded slice t of the reference's own sparse run (examples/data/sparse_test/log.jld, full_cov = true,
+    L = 10, M = 20, H = 2) is loaded on the device, ONE sweep is run there, and the result is compared with recorded slice
+    t + 1 -- updateA! full branch (:178-202; the device inverts the M diagonal H x H blocks of the reference's dense
+    40 x 40 matrix), updateB!, updateCA!, updateCB!, updateSigma!.  fp32 Y and fp32-stored factors: 1e-5."""
+    import os
+    g = np.load(os.path.join(golden_dir, "sparse_test.npz"))
+    Y = np.ascontiguousarray(g["Y"])
+    pkg.set_defaults(y_dtype=pkg.VBMF_Y_F32, factor_dtype=pkg.VBMF_FACTOR_AUTO)
+    worst = {}
+    for t in range(0, 100):
+        p = _fixture_params(pkg, g, t)
+        pkg.vbmf_sparse_(Y, p, 1, eps=0.0, full_cov=True, est_cb=True)
+        for f in RFIELDS:
+            worst[f] = max(worst.get(f, 0.0), relF(getattr(p, f), g[f][t + 1]))
+        for f in ("sigmaHat", "zeta"):
+            worst[f] = max(worst.get(f, 0.0), abs(getattr(p, f) - g[f][t + 1]) / abs(g[f][t + 1]))
+    report("sparse full_cov, one device sweep from each of the reference's 100 recorded slices, worst: "
+           + " ".join(f"{k}={v:.2e}" for k, v in worst.items()))
+    assert max(worst.values()) < 1e-5, worst
+    # the blocks the device inverted are the diagonal blocks of the recorded dense covariance
+    cov = {int(s): i for i, s in enumerate(g["cov_slices"])}
+    t = max(s for s in cov if s > 0)
+    p = _fixture_params(pkg, g, t - 1)
+    pkg.sparse_updateA_(Y, p, full_cov=True)
+    S = g["SigmaATVec"][cov[t]]
+    H, M = p.H, p.M
+    assert relF(p.diagSigmaATVec, np.diag(S)) < 1e-5
+    assert relF(p.SigmaA, sum(S[m * H:(m + 1) * H, m * H:(m + 1) * H] for m in range(M))) < 1e-5
+    off = S.copy()
+    for m in range(M):
+        off[m * H:(m + 1) * H, m * H:(m + 1) * H] = 0.0
+    assert np.all(off == 0.0)                                   # the recorded matrix IS block diagonal
+
+
+def test_full_cov_logged_trajectory_against_the_reference_record(pkg, golden_dir, tmp_path):
+    """PINNED: the reference's recorded sparse experiment run on the device from slice 0 with per-sweep logging
+    (vbmf_sparse!(...; full_cov = true, logdir = ...)); every one of the 101 slices is compared with the reference's log."""
+    import os
+    g = np.load(os.path.join(golden_dir, "sparse_test.npz"))
+    Y = np.ascontiguousarray(g["Y"])
+    pkg.set_defaults(y_dtype=pkg.VBMF_Y_F32, factor_dtype=pkg.VBMF_FACTOR_AUTO)
+    p = _fixture_params(pkg, g, 0)
+    d = pkg.vbmf_sparse_(Y, p, 100, eps=0.0, full_cov=True, est_cb=True, logdir=str(tmp_path), desc="sparse_fixture")
+    log, Yl, _ = pkg.load_log(os.path.join(str(tmp_path), "sparse_fixture"))
+    assert p._last_run[0] == 100 and np.array_equal(Yl, Y) and log["AHat"].shape == (20, 2, 101)
+    worst = {}
+    for f in RFIELDS:
+        worst[f] = max(relF(log[f][..., t], g[f][t]) for t in range(101))
+    worst["sigmaHat"] = float(np.max(np.abs(log["sigmaHat"] - g["sigmaHat"]) / g["sigmaHat"]))
+    report("sparse full_cov logged trajectory vs the reference's recorded log, worst slice: "
+           + " ".join(f"{k}={v:.2e}" for k, v in worst.items()))
+    assert max(worst.values()) < 2e-3, worst
+    assert abs(p.sigmaHat - 4.60278260971759) < 2e-3 * 4.6           # SURVEY Appendix B known-answer values
+    assert abs(p.zeta - 21.72598805535064) < 2e-3 * 21.7
+
+
+@pytest.mark.parametrize("L,M,H", [(300, 170, 5), (500, 120, 40), (400, 90, 64)])
+def test_full_cov_against_the_oracle(pkg, L, M, H):
+    """Larger shapes (all three register tilings of the per-column inverse), label mask included, against the oracle's
+    dense kron(...) restatement; then 6 sweeps of the loop."""
+    Y, po = _mk(L, M, H, 60 + H, H1=2, labels=[3, 50, 80])
+    pkg.set_defaults(y_dtype=pkg.VBMF_Y_F32, factor_dtype=pkg.VBMF_FACTOR_AUTO)
+    Yf = Y.astype(np.float32).astype(np.float64)
+    po.trYTY = float(np.sum(Yf * Yf))
+    O.vbmf_sparse_(Yf, po, 2, eps=0.0, full_cov=False)           # a state with non-trivial SigmaB / CA
+    pg = _to_pkg(pkg, po)
+    pkg.sparse_updateA_(Yf, pg, full_cov=True); O.sparse_updateA(Yf, po, full_cov=True)
+    _cmp(f"full_cov {L}x{M} H{H} updateA", pg, po, 5e-5, ("ATVecHat", "diagSigmaATVec", "SigmaA"))
+    assert np.any(po.SigmaA != np.diag(np.diag(po.SigmaA)))     # a full matrix now
+    assert np.all(pg.AHat[[3, 50, 80], H - 2:] == 0.0)
+    pg = _to_pkg(pkg, po)
+    pkg.sparse_updateB_(Yf, pg); O.sparse_updateB(Yf, po)        # consumes the full SigmaA
+    _cmp(f"full_cov {L}x{M} H{H} updateB", pg, po, 5e-5, ("BHat", "SigmaB"))
+    if M * H <= 4000:                                            # the oracle's dense inverse is O((MH)^3)
+        pg = _to_pkg(pkg, po)
+        pkg.vbmf_sparse_(Yf, pg, 6, eps=0.0, full_cov=True)
+        O.vbmf_sparse_(Yf, po, 6, eps=0.0, full_cov=True)
+        _cmp(f"full_cov {L}x{M} H{H} run6", pg, po, 1e-3)
+    with pytest.raises(NotImplementedError):
+        pkg.sparse_updateA_(Yf, pg, full_cov=True, diag_var=True)

@@ -398,10 +398,21 @@ def _sparse_ctx(Y, p, diag_var=False, dual=False, trial=False):
     return c
 
 
-def _spush(c, p, diag_var=False):
+def _push_SigmaA(c, p, full_cov):
+    """full_cov on/off for the calls that follow; a non-diagonal SigmaA (a full_cov state) is handed over as it is
+    (vbmf_sparse_set_state derives a diagonal one from diagSigmaATVec)."""
+    c.sparse_set_full_cov(full_cov)
+    S = None if p.SigmaA is None else np.asarray(p.SigmaA)
+    if S is not None and (full_cov or np.any(S != np.diag(np.diag(S)))):
+        c.sparse_set_SigmaA(S)
+
+
+def _spush(c, p, diag_var=False, full_cov=False):
     hyper = dict(alpha0=p.alpha0, beta0=p.beta0, gamma0=p.gamma0, delta0=p.delta0, eta0=p.eta0, zeta0=p.zeta0)
     c.sparse_set_state(p.ATVecHat, p.diagSigmaATVec, p.CA, p.beta, p.BHat, p.SigmaB, p.CB, p.delta, p.sigmaHat,
                        p.zeta, hyper, labels0=_labels0(p), H1=p.H1)
+    if not diag_var:
+        _push_SigmaA(c, p, full_cov)
     if diag_var:
         c.sparse_set_noise_rows(p.sigmaVecHat, p.zetaVec, float(np.asarray(p.etaVec).reshape(-1)[0]))
 
@@ -412,24 +423,29 @@ def _spull(c, p, diag_var=False):
         p.sigmaVecHat, p.zetaVec = c.sparse_get_noise_rows()
     p.ATVecHat, p.diagSigmaATVec, p.CA, p.beta = s["ATVecHat"], s["diagSigmaATVec"], s["CA"], s["beta"]
     p.AHat = p.ATVecHat.reshape(p.M, p.H).copy()
-    p.SigmaA = np.diag(s["SigmaA_diag"])
+    p.SigmaA = np.ascontiguousarray(c.sparse_get_SigmaA())          # diagonal in the diagonal branch, full under full_cov
     p.BHat, p.SigmaB, p.CB, p.delta = s["BHat"], s["SigmaB"], s["CB"], s["delta"]
     if not diag_var:
         p.sigmaHat, p.zeta = s["sigmaHat"], s["zeta"]
 
 
-def _sone(Y, p, which, diag_var=False):
+def _check_full_cov(full_cov, diag_var, H):
+    if full_cov and (diag_var or H > 64):
+        raise NotImplementedError("full_cov=true is built for diag_var=false and H <= 64")
+
+
+def _sone(Y, p, which, diag_var=False, full_cov=False):
     c = _sparse_ctx(Y, p, diag_var)
-    _spush(c, p, diag_var)
+    _spush(c, p, diag_var, full_cov)
     c.sparse_step(which)
     _spull(c, p, diag_var)
 
 
 def sparse_updateA_(Y, params, full_cov=False, diag_var=False):
-    """updateA! -- src/vbmf_sparse.jl:176-247 (diagonal branch only)."""
-    if full_cov:
-        raise NotImplementedError("only full_cov=false is built (SURVEY.md section 2)")
-    _sone(Y, params, SSTEP_A, diag_var)
+    """updateA! -- src/vbmf_sparse.jl:176-247.  full_cov=true (:178-202): the M diagonal blocks of the reference's dense
+    MH x MH covariance, inverted one per column on the device; SigmaATVec/invSigmaATVec are not materialised."""
+    _check_full_cov(full_cov, diag_var, params.H)
+    _sone(Y, params, SSTEP_A, diag_var, full_cov)
 
 
 def sparse_updateB_(Y, params, diag_var=False):
@@ -455,10 +471,9 @@ def sparse_updateSigma_(Y, params, diag_var=False):
 def vbmf_sparse_(Y, params, niter, eps=1e-6, diag_var=False, full_cov=False, logdir="", desc="", verb=False, est_cb=True,
                  log_every=1):
     """vbmf_sparse! -- src/vbmf_sparse.jl:344-410.  Returns d (like the reference).  logdir: see vbmf_."""
-    if full_cov:
-        raise NotImplementedError("only full_cov=false is built (SURVEY.md section 2)")
+    _check_full_cov(full_cov, diag_var, params.H)
     c = _sparse_ctx(Y, params, diag_var)
-    _spush(c, params, diag_var)
+    _spush(c, params, diag_var, full_cov)
     if logdir != "":
         logVar = create_log(params)
         i, d, iters = 1, eps + 1.0, 0
@@ -952,8 +967,8 @@ def vbls_(Y, params, niter, diag_var=False, full_cov=False):
     """vbls! -- examples/mil_util.jl:179-203: solves Y = B A' + E for A with B (and SigmaB, CB) fixed: niter x
     (updateA!, updateCA!, updateSigma2! / updateSigma!), then updateYHat!; returns params.AHat.
     On the device Y'B is formed once per call (B is fixed), so the call reads Y once, not 2 x niter times."""
-    if full_cov:
-        raise NotImplementedError("only full_cov=false is built (SURVEY.md section 2)")
+    if full_cov and not isinstance(params, vbmf_sparse_parameters):
+        raise NotImplementedError("full_cov=true is built for the sparse model's calls only")
     if isinstance(params, vbmf_dual_parameters):                         # examples/mil_util.jl:190-193
         c = _sparse_ctx(Y, params, diag_var, dual=True)
         _dpush(c, params, diag_var)
@@ -970,8 +985,9 @@ def vbls_(Y, params, niter, diag_var=False, full_cov=False):
         params.YHat = params.BHat @ params.AHat.T if params.L * params.M <= YHAT_AUTO_LIMIT else None
         return params.AHat
     if isinstance(params, vbmf_sparse_parameters):
+        _check_full_cov(full_cov, diag_var, params.H)
         c = _sparse_ctx(Y, params, diag_var)
-        _spush(c, params, diag_var)
+        _spush(c, params, diag_var, full_cov)
         c.sparse_run_fixed_basis(int(niter))
         _spull(c, params, diag_var)
         params.YHat = params.BHat @ params.AHat.T if params.L * params.M <= YHAT_AUTO_LIMIT else None

@@ -30,6 +30,7 @@ SYMBOLS = [
     "vbmf_sparse_lower_bound", "vbmf_sparse_set_noise_rows", "vbmf_sparse_get_noise_rows", "vbmf_preprocess_open", "vbmf_preprocess_rows", "vbmf_set_Y_preprocessed",
     "vbmf_preprocess_close", "vbmf_dual_set_priors", "vbmf_dual_get_priors", "vbmf_dual_run",
     "vbmf_trial_set_priors", "vbmf_trial_get_priors", "vbmf_trial_run",
+    "vbmf_sparse_set_full_cov", "vbmf_sparse_set_SigmaA", "vbmf_sparse_get_SigmaA",
 ]
 SSTEP_A, SSTEP_B, SSTEP_CA, SSTEP_CB, SSTEP_SIGMA, SSTEP_PRIORS = 1, 2, 4, 8, 16, 32
 PEEK_P, PEEK_Q, PEEK_A32, PEEK_B32, PEEK_FA, PEEK_FB, PEEK_Y1, PEEK_Y2, PEEK_DIMS = range(9)
@@ -114,6 +115,9 @@ def lib():
     L.vbmf_sparse_step.argtypes = [vp, i32]
     L.vbmf_sparse_run.argtypes = [vp, i64, C.c_double, i32, C.POINTER(i64), dp, dp]
     L.vbmf_sparse_lower_bound.argtypes = [vp, i32, dp]
+    L.vbmf_sparse_set_full_cov.argtypes = [vp, i32]
+    L.vbmf_sparse_set_SigmaA.argtypes = [vp, dp]
+    L.vbmf_sparse_get_SigmaA.argtypes = [vp, dp]
     L.vbmf_dual_set_priors.argtypes = [vp, i64] + [C.c_double] * 6
     L.vbmf_dual_get_priors.argtypes = [vp, C.POINTER(i64), dp]
     L.vbmf_dual_run.argtypes = [vp, i64, C.c_double, i32, i32, C.POINTER(i64), dp, dp]
@@ -341,6 +345,18 @@ class Context:
         s, z = np.empty(self.L), np.empty(self.L)
         self._chk(self._lib.vbmf_sparse_get_noise_rows(self._h, _dptr(s), _dptr(z)))
         return s, z
+
+    def sparse_set_full_cov(self, on=True):
+        self._chk(self._lib.vbmf_sparse_set_full_cov(self._h, int(bool(on))))
+
+    def sparse_set_SigmaA(self, SigmaA):
+        S = _fcol(SigmaA, (self.H, self.H))
+        self._chk(self._lib.vbmf_sparse_set_SigmaA(self._h, _dptr(S)))
+
+    def sparse_get_SigmaA(self):
+        S = np.empty((self.H, self.H), order="F")
+        self._chk(self._lib.vbmf_sparse_get_SigmaA(self._h, _dptr(S)))
+        return S
 
     def sparse_lower_bound(self, clamp=True):
         v = C.c_double()

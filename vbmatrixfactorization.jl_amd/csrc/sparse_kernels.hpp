@@ -63,6 +63,97 @@ __global__ __launch_bounds__(256) void sparse_update_a_kernel(const float* __res
     }
 }
 
+// ---- full_cov = true (src/vbmf_sparse.jl:178-202, src/vbmf_dual.jl:218-243, src/vbmf_trial.jl:252-277) ------------------
+// The reference builds invSigmaATVec = sigmaHat * kron(I_M, B'B + L SigmaB) + diag(CA) as a dense MH x MH matrix and
+// inverts it.  That matrix is BLOCK DIAGONAL: M independent H x H blocks  K_m = sigmaHat (B'B + L SigmaB) + diag(CA[m,:]),
+// so  Sigma_m = inv(K_m),  vec(A')[m,:] = sigmaHat Sigma_m (B'Y)[:,m],  diagSigmaATVec[m,:] = diag(Sigma_m),
+// SigmaA = sum_m Sigma_m  (a full H x H matrix here) -- the per-column posterior update with the small covariance
+// inverted in LDS/registers by one workgroup per column (gj_tiled).  The dense matrix is never formed.
+// Block b walks columns m = b, b + grid, ...; its sum of Sigma_m goes to part[b] (folded in fixed order afterwards).
+template <int R, int T>
+__global__ __launch_bounds__(T * T) void sparse_update_a_full_kernel(const float* __restrict__ P, long long ldP,
+                                                                     const float* __restrict__ CA32,
+                                                                     const double* __restrict__ st, StateLayout lay,
+                                                                     float* __restrict__ A32, float* __restrict__ dS32,
+                                                                     const unsigned char* __restrict__ mask, int hmask_start,
+                                                                     long long M, int H, int Hp, double Lg,
+                                                                     double* __restrict__ part, int* __restrict__ ints) {
+    extern __shared__ __attribute__((aligned(16))) double lds_full[];
+    if (load_stop(ints)) return;
+    constexpr int NP = T * R;
+    const int tx = threadIdx.x % T, ty = threadIdx.x / T;
+    double* strip = lds_full;                 // 4 * NP
+    double* pivs = lds_full + 4 * NP;         // NP
+    double* pv = lds_full + 5 * NP;           // NP: (B'Y)[:, m]
+    const double sig = st[lay.scal() + S_SIGMA2];
+    double k0[R][R], acc[R][R];
+#pragma unroll
+    for (int a = 0; a < R; ++a)
+#pragma unroll
+        for (int b = 0; b < R; ++b) {
+            const int i = ty + T * a, j = tx + T * b;
+            k0[a][b] = (i < H && j < H) ? sig * (st[lay.GB() + (long long)i * lay.Hp + j] + Lg * st[lay.SB() + (long long)i * lay.Hp + j]) : 0.0;
+            acc[a][b] = 0.0;
+        }
+    int bad = 0;
+    for (long long m = blockIdx.x; m < M; m += gridDim.x) {
+        double w[R][R];
+#pragma unroll
+        for (int a = 0; a < R; ++a)
+#pragma unroll
+            for (int b = 0; b < R; ++b) {
+                const int i = ty + T * a, j = tx + T * b;
+                double v = (i == j) ? 1.0 : 0.0;                        // identity padding
+                if (i < H && j < H) v = k0[a][b] + ((i == j) ? (double)CA32[m * Hp + i] : 0.0);
+                w[a][b] = v;
+            }
+        for (int h = threadIdx.x; h < NP; h += T * T) pv[h] = h < H ? (double)P[(long long)h * ldP + m] : 0.0;
+        gj_tiled<R, T>(w, H, strip, pivs);
+        __syncthreads();                                                // pv and pivs complete
+        for (int k = threadIdx.x; k < H; k += T * T) { const double q = pivs[k]; if (!(q > 0.0) || !isfinite(q)) bad = 1; }
+#pragma unroll
+        for (int a = 0; a < R; ++a) {
+            const int i = ty + T * a;
+            double sm = 0.0;
+#pragma unroll
+            for (int b = 0; b < R; ++b) sm += w[a][b] * pv[tx + T * b];
+            for (int off = T / 2; off > 0; off >>= 1) sm += __shfl_xor(sm, off);       // the T lanes of a row are contiguous
+            if (tx == 0 && i < H) {
+                float av = (float)(sig * sm);
+                if (mask != nullptr && i >= hmask_start && mask[m]) av = 0.f;
+                A32[m * Hp + i] = av;
+            }
+#pragma unroll
+            for (int b = 0; b < R; ++b) {
+                const int j = tx + T * b;
+                if (i < H && j < H) {
+                    acc[a][b] += w[a][b];
+                    if (i == j) dS32[m * Hp + i] = (float)w[a][b];
+                }
+            }
+        }
+        __syncthreads();                                                // LDS is rewritten by the next column
+    }
+    if (bad) atomicExch(ints + I_ERR, 1);
+#pragma unroll
+    for (int a = 0; a < R; ++a)
+#pragma unroll
+        for (int b = 0; b < R; ++b) {
+            const int i = ty + T * a, j = tx + T * b;
+            if (i < Hp && j < Hp) part[(long long)blockIdx.x * Hp * Hp + (long long)i * Hp + j] = acc[a][b];
+        }
+}
+// SigmaA = sum over the blocks' partial sums, fixed order
+__global__ __launch_bounds__(256) void full_sa_fold_kernel(const double* __restrict__ part, int nblocks, int Hp,
+                                                           double* __restrict__ st, StateLayout lay, const int* __restrict__ stop) {
+    if (stop && *stop) return;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= Hp * Hp) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += part[(long long)b * Hp * Hp + e];
+    st[lay.SA() + e] = s;
+}
+
 // Grouped models (src/vbmf_dual.jl:322-351, src/vbmf_trial.jl:357-400): the entries of vec(A') fall into up to three
 // groups with their own Gamma hyper-prior -- g = 0: columns h < H0 (all rows); g = 1: h >= H0, rows m < M0; g = 2:
 // h >= H0, rows m >= M0 (vbmf_dual: M0 = M, two groups).  Priors (alpha0g, beta0g) at scal[S_GPRI + 2g, +1], read from

@@ -76,8 +76,12 @@ struct vbmf_ctx {
     bool dual = false;               // grouped model: VBMF_VARIANT_DUAL_DIAG (two groups) or VBMF_VARIANT_TRIAL_DIAG (three)
     bool trial = false;
     int64_t H0 = 0, M0 = 0;          // group 0: columns h < H0; groups 1 / 2: the other columns of rows m < M0 / m >= M0
-    double* gpart = nullptr;         // per-block [sum log beta, sum CA] x 2 groups
+    double* gpart = nullptr;         // per-block [sum log beta, sum CA] per group
     int gpart_blocks = 0;
+    // full_cov = true: block-diagonal posterior of vec(A') (one H x H inverse per column of Y)
+    bool full_cov = false;
+    double* fpart = nullptr;         // per-block sums of Sigma_m
+    int fblocks = 0;
     vbmf_sparse_hyper hyp{};
     double alpha = 0, gamma_ = 0, eta = 0;
     StateLayout lay{};
@@ -783,7 +787,7 @@ int vbmf_destroy(vbmf_ctx* c) {
     if (c->comm) ncclCommDestroy(c->comm);
     void* bufs[] = {c->Y1, c->Y2, c->FA_alloc, c->FB_alloc, c->P, c->Q, c->Pred, c->A32, c->B32[0], c->B32[1], c->SA32,
                     c->SB32, c->gslab, c->st, c->gtmp, c->ypart, c->ints, c->mask, c->dS32, c->CA32, c->beta32, c->vtab,
-                    c->sigv, c->zetav, c->yrow, c->hpart, c->vsq, c->sig32, c->G32, c->FBs_alloc, c->gpart};
+                    c->sigv, c->zetav, c->yrow, c->hpart, c->vsq, c->sig32, c->G32, c->FBs_alloc, c->gpart, c->fpart};
     for (void* b : bufs) if (b) hipFree(b);
     if (c->ints_host) hipHostFree(c->ints_host);
     if (c->scal_host) hipHostFree(c->scal_host);
@@ -1638,6 +1642,13 @@ static int sparse_colsum(vbmf_ctx* c) {
     return VBMF_OK;
 }
 
+template <int R, int T>
+static void launch_full_a_t(vbmf_ctx* c) {
+    hipLaunchKernelGGL((sparse_update_a_full_kernel<R, T>), dim3(c->fblocks), dim3(T * T), (size_t)(6 * T * R) * sizeof(double), c->stream,
+                       c->Pred, (long long)c->d1.XT * 32, c->CA32, c->st, c->lay, c->A32, c->dS32, c->has_mask ? c->mask : nullptr,
+                       (int)(c->H - c->H1), (long long)c->M, (int)c->H, c->Hp, (double)c->Lg, c->fpart, c->ints);
+}
+
 static int do_sparse_update_A(vbmf_ctx* c, bool reuse_P = false) {
     TRY(ensure_gram_B(c));
     const int* stop = c->ints + I_STOP;
@@ -1660,6 +1671,22 @@ static int do_sparse_update_A(vbmf_ctx* c, bool reuse_P = false) {
         if (sharded(c)) TRY(allreduce_sum(c, c->Pred, (size_t)n, false));      // Y'B summed over the row shards
     }
     TRY(side_join(c));                              // the previous sweep's lambda_max / CB / sigma / stop test (side stream)
+    if (c->full_cov) {
+        // :178-202 -- M independent H x H inverses (the dense MH x MH matrix of the reference is block diagonal)
+        const int H = (int)c->H;
+        if (H <= 16) launch_full_a_t<1, 16>(c);
+        else if (H <= 32) launch_full_a_t<2, 16>(c);
+        else launch_full_a_t<4, 16>(c);
+        hipLaunchKernelGGL(full_sa_fold_kernel, dim3(cdiv(c->Hp * c->Hp, 256)), dim3(256), 0, c->stream, c->fpart, c->fblocks, c->Hp, c->st, c->lay, stop);
+        HIPCHK(c, hipGetLastError());
+        TRY(launch_retile(c, 0, true));
+        TRY(launch_gram(c, 0, c->A32, nullptr, true));
+        c->gA_valid = true;
+        c->P_valid = true;
+        c->Q_valid = false;
+        c->kb_identity = false;
+        return VBMF_OK;
+    }
     hipLaunchKernelGGL(sparse_v_kernel, dim3((c->Hp + 63) / 64), dim3(64), 0, c->stream, c->st, c->lay, (int)c->H, (double)c->Lg, c->vtab,
                        c->diagvar ? (const double*)c->vsq : (const double*)nullptr, stop);
     const int compat = (c->o.reference_compat & VBMF_COMPAT_SPARSE_REPEAT) ? 1 : 0;
@@ -2002,6 +2029,47 @@ static int sparse_run_impl(vbmf_ctx* c, int64_t niter, double eps, int est_cb, i
 int vbmf_sparse_run(vbmf_ctx* c, int64_t niter, double eps, int est_cb, int64_t* iters_done, double* d_last,
                     double* trace) {
     return sparse_run_impl(c, niter, eps, est_cb, 0, iters_done, d_last, trace);
+}
+
+// full_cov = true of updateA! (src/vbmf_sparse.jl:178-202): homoscedastic models, H <= 64
+int vbmf_sparse_set_full_cov(vbmf_ctx* c, int on) {
+    if (!c) return VBMF_ERR_INVALID;
+    if (!c->sparse) FAIL(c, VBMF_ERR_INVALID, "not a sparse context");
+    if (on && c->diagvar) FAIL(c, VBMF_ERR_UNSUPPORTED, "full_cov with diag_var is not built");
+    if (on && c->H > 64) FAIL(c, VBMF_ERR_UNSUPPORTED, "full_cov is built for H <= 64");
+    HIPCHK(c, hipSetDevice(c->o.device));
+    if (on && !c->fpart) {
+        c->fblocks = (int)std::min<int64_t>(c->M, 1024);
+        const size_t bytes = (size_t)c->fblocks * c->Hp * c->Hp * 8;
+        HIPCHK(c, hipMalloc((void**)&c->fpart, bytes));
+        HIPCHK(c, hipMemset(c->fpart, 0, bytes));
+    }
+    c->full_cov = on != 0;
+    return VBMF_OK;
+}
+
+// SigmaA as a full H x H matrix (column-major): the diagonal branch keeps it diagonal, the full branch does not, and
+// vbmf_sparse_set_state derives it from diagSigmaATVec -- a caller continuing a full_cov state sets it explicitly.
+int vbmf_sparse_set_SigmaA(vbmf_ctx* c, const double* SigmaA) {
+    if (!c || !SigmaA) return VBMF_ERR_INVALID;
+    if (!c->sparse || !c->haveState) FAIL(c, VBMF_ERR_INVALID, "no sparse state");
+    HIPCHK(c, hipSetDevice(c->o.device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    TRY(upload_small(c, SigmaA, c->lay.SA(), true));
+    c->kb_identity = false;
+    return VBMF_OK;
+}
+
+int vbmf_sparse_get_SigmaA(vbmf_ctx* c, double* SigmaA) {
+    if (!c || !SigmaA) return VBMF_ERR_INVALID;
+    if (!c->sparse || !c->haveState) FAIL(c, VBMF_ERR_INVALID, "no sparse state");
+    HIPCHK(c, hipSetDevice(c->o.device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<double> buf((size_t)c->Hp * c->Hp);
+    HIPCHK(c, hipMemcpy(buf.data(), c->st + c->lay.SA(), buf.size() * 8, hipMemcpyDeviceToHost));
+    for (int64_t j = 0; j < c->H; ++j)
+        for (int64_t i = 0; i < c->H; ++i) SigmaA[i + j * c->H] = buf[(size_t)i * c->Hp + j];
+    return VBMF_OK;
 }
 
 // ---- grouped ARD variants (src/vbmf_dual.jl, src/vbmf_trial.jl; full_cov=false, diag_var=false) -------------------
