@@ -606,9 +606,9 @@ def vbmf_dual_init(Y, H, H0, ca=1.0, alpha0=1e-10, beta0=1e-10, cb=1.0, gamma0=1
     return p
 
 
-def dual_updateA(Y, p, reference_compat=True, diag_var=False):
-    """src/vbmf_dual.jl:245-284: the sparse model's diagonal branch, no label mask, then the A0/A1 views."""
-    sparse_updateA(Y, p, full_cov=False, reference_compat=reference_compat, diag_var=diag_var)
+def dual_updateA(Y, p, reference_compat=True, diag_var=False, full_cov=False):
+    """src/vbmf_dual.jl:216-284: the sparse model's updateA! (either branch), no label mask, then the A0/A1 views."""
+    sparse_updateA(Y, p, full_cov=full_cov, reference_compat=reference_compat, diag_var=diag_var)
     p.A0Hat, p.A1Hat = p.AHat[:, :p.H0].copy(), p.AHat[:, p.H0:].copy()
 
 
@@ -654,13 +654,14 @@ def dual_updatePriors(p):
         p.beta01 = n1 * p.alpha01 / float(np.sum(p.CA1))                 # :432-434
 
 
-def vbmf_dual_(Y, p, niter, eps=1e-6, est_cb=True, est_priors=True, reference_compat=True, diag_var=False, trace=None):
+def vbmf_dual_(Y, p, niter, eps=1e-6, est_cb=True, est_priors=True, reference_compat=True, diag_var=False, trace=None,
+               full_cov=False):
     """vbmf_dual! -- src/vbmf_dual.jl:455-530 (full_cov=false, convergence on BHat).  Returns (d, iterations)."""
     old = p.BHat.copy()
     d = eps + 1.0
     i = 1
     while i <= niter and d > eps:
-        dual_updateA(Y, p, reference_compat=reference_compat, diag_var=diag_var)
+        dual_updateA(Y, p, reference_compat=reference_compat, diag_var=diag_var, full_cov=full_cov)
         sparse_updateB(Y, p, diag_var=diag_var)                          # :292-306
         dual_updateCA(p)
         if est_cb:
@@ -809,9 +810,9 @@ def vbmf_trial_init(Y, H, H0, M0, ca=1.0, alpha0=1e-10, beta0=1e-10, cb=1.0, gam
     return p
 
 
-def trial_updateA(Y, p, reference_compat=True, diag_var=False):
-    """src/vbmf_trial.jl:250-320: the sparse model's diagonal branch, no label mask, then the A1/A2/A3 views."""
-    sparse_updateA(Y, p, full_cov=False, reference_compat=reference_compat, diag_var=diag_var)
+def trial_updateA(Y, p, reference_compat=True, diag_var=False, full_cov=False):
+    """src/vbmf_trial.jl:250-320: the sparse model's updateA! (either branch), no label mask, then the A1/A2/A3 views."""
+    sparse_updateA(Y, p, full_cov=full_cov, reference_compat=reference_compat, diag_var=diag_var)
     p.A1Hat, p.A2Hat, p.A3Hat = p.AHat[:, :p.H0].copy(), p.AHat[:p.M0, p.H0:].copy(), p.AHat[p.M0:, p.H0:].copy()
 
 
@@ -843,13 +844,14 @@ def trial_updatePriors(p):
         p.beta03 = n[2] * p.alpha03 / float(np.sum(p.CA3))
 
 
-def vbmf_trial_(Y, p, niter, eps=1e-6, est_cb=True, est_priors=True, reference_compat=True, trace=None, diag_var=False):
+def vbmf_trial_(Y, p, niter, eps=1e-6, est_cb=True, est_priors=True, reference_compat=True, trace=None, diag_var=False,
+                full_cov=False):
     """vbmf_trial! -- src/vbmf_trial.jl:528-604 (full_cov=false).  Returns (d, iterations)."""
     old = p.BHat.copy()
     d = eps + 1.0
     i = 1
     while i <= niter and d > eps:
-        trial_updateA(Y, p, reference_compat=reference_compat, diag_var=diag_var)
+        trial_updateA(Y, p, reference_compat=reference_compat, diag_var=diag_var, full_cov=full_cov)
         sparse_updateB(Y, p, diag_var=diag_var)                          # :327-341
         trial_updateCA(p)
         if est_cb:

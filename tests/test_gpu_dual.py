@@ -229,3 +229,18 @@ def test_dual_heteroscedastic_run(pkg, mode):
     for _ in range(4):                                                      # examples/mil_util.jl:190-193
         O.dual_updateA(Ys, po, diag_var=True); O.dual_updateCA(po); O.sparse_updateSigma(Ys, po, diag_var=True)
     _cmp(f"diag_var vbls4 {mode}", pg, po, tol, ("ATVecHat", "diagSigmaATVec", "SigmaA", "CA", "beta", "sigmaVecHat", "zetaVec"))
+
+
+def test_dual_full_cov_as_the_mil_callers_run_it(pkg):
+    """examples/mil_util.jl:345-351 runs vbmf_dual! with full_cov = true (M*H <= 3200) and est_priors: the per-column
+    H x H blocks on the device against the oracle's dense kron(...) restatement."""
+    L, M, H, H0 = 300, 160, 6, 4
+    Y, po = _mk(L, M, H, H0, 61)
+    pkg.set_defaults(y_dtype=pkg.VBMF_Y_F32, factor_dtype=pkg.VBMF_FACTOR_AUTO)
+    Yf = Y.astype(np.float32).astype(np.float64)
+    po.trYTY = float(np.sum(Yf * Yf))
+    pg = _to_pkg(pkg, po)
+    d_gpu = pkg.vbmf_dual_(Yf, pg, 10, eps=0.0, full_cov=True, est_priors=True)
+    d_ref, n = O.vbmf_dual_(Yf, po, 10, eps=0.0, full_cov=True, est_priors=True)
+    _cmp("full_cov run10 f32", pg, po, 2e-3, priors_tol=2e-3)
+    assert np.any(pg.SigmaA != np.diag(np.diag(pg.SigmaA))) and abs(d_gpu - d_ref) <= 2e-2 * d_ref + 2e-6

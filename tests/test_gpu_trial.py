@@ -196,3 +196,17 @@ def test_trial_heteroscedastic_run(pkg):
     _cmp("diag_var run8 f32", pg, po, 2e-3, FIELDS + ("sigmaVecHat", "zetaVec"), priors_tol=2e-3)
     assert pg._last_run[0] == 8 and abs(d_gpu - d_ref) <= 2e-2 * d_ref + 2e-6
     assert np.corrcoef(np.log(pg.sigmaVecHat), np.log(po.sigmaVecHat))[0, 1] > 0.999
+
+
+def test_trial_full_cov_run(pkg):
+    """vbmf_trial! with full_cov = true (src/vbmf_trial.jl:252-277) and the prior fits."""
+    L, M, H, H0, M0 = 300, 160, 6, 4, 70
+    Y, po = _mk(L, M, H, H0, M0, 63)
+    pkg.set_defaults(y_dtype=pkg.VBMF_Y_F32, factor_dtype=pkg.VBMF_FACTOR_AUTO)
+    Yf = Y.astype(np.float32).astype(np.float64)
+    po.trYTY = float(np.sum(Yf * Yf))
+    pg = _to_pkg(pkg, po)
+    d_gpu = pkg.vbmf_trial_(Yf, pg, 10, eps=0.0, full_cov=True, est_priors=True)
+    d_ref, n = O.vbmf_trial_(Yf, po, 10, eps=0.0, full_cov=True, est_priors=True)
+    _cmp("full_cov run10 f32", pg, po, 2e-3, priors_tol=2e-3)
+    assert np.any(pg.SigmaA != np.diag(np.diag(pg.SigmaA))) and abs(d_gpu - d_ref) <= 2e-2 * d_ref + 2e-6

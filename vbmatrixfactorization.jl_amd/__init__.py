@@ -612,10 +612,12 @@ def vbmf_dual_init(Y, H, H0, ca=1.0, alpha0=1e-10, beta0=1e-10, cb=1.0, gamma0=1
     return p
 
 
-def _dpush(c, p, diag_var=False):
+def _dpush(c, p, diag_var=False, full_cov=False):
     hyper = dict(alpha0=p.alpha00, beta0=p.beta00, gamma0=p.gamma0, delta0=p.delta0, eta0=p.eta0, zeta0=p.zeta0)
     c.sparse_set_state(p.ATVecHat, p.diagSigmaATVec, p.CA, p.beta, p.BHat, p.SigmaB, p.CB, p.delta, p.sigmaHat, p.zeta, hyper)
     c.dual_set_priors(p.H0, p.alpha00, p.beta00, p.alpha01, p.beta01, p.alpha0, p.alpha1)
+    if not diag_var:
+        _push_SigmaA(c, p, full_cov)
     if diag_var:
         c.sparse_set_noise_rows(p.sigmaVecHat, p.zetaVec, float(np.asarray(p.etaVec).reshape(-1)[0]))
 
@@ -629,7 +631,7 @@ def _dpull(c, p, diag_var=False):
     p.A0Hat, p.A1Hat = p.AHat[:, :p.H0].copy(), p.AHat[:, p.H0:].copy()
     p.CA0, p.CA1 = _dual_split(p.CA, p.M, p.H, p.H0)
     p.beta0, p.beta1 = _dual_split(p.beta, p.M, p.H, p.H0)
-    p.SigmaA = np.diag(s["SigmaA_diag"])
+    p.SigmaA = np.ascontiguousarray(c.sparse_get_SigmaA())
     p.BHat, p.SigmaB, p.CB, p.delta = s["BHat"], s["SigmaB"], s["CB"], s["delta"]
     if not diag_var:
         p.sigmaHat, p.zeta = s["sigmaHat"], s["zeta"]
@@ -644,19 +646,18 @@ def _dpull_priors(c, p):
     p.alpha = np.array([p.alpha0, p.alpha1])
 
 
-def _done(Y, p, which, diag_var=False):
+def _done(Y, p, which, diag_var=False, full_cov=False):
     c = _sparse_ctx(Y, p, diag_var, dual=True)
-    _dpush(c, p, diag_var)
+    _dpush(c, p, diag_var, full_cov)
     c.sparse_step(which)
     _dpull(c, p, diag_var)
     _dpull_priors(c, p)
 
 
 def dual_updateA_(Y, params, full_cov=False, diag_var=False):
-    """updateA! -- src/vbmf_dual.jl:216-285 (diagonal branch)."""
-    if full_cov:
-        raise NotImplementedError("only full_cov=false is built")
-    _done(Y, params, SSTEP_A, diag_var)
+    """updateA! -- src/vbmf_dual.jl:216-285 (full_cov=true, :218-243: per-column blocks, see sparse_updateA_)."""
+    _check_full_cov(full_cov, diag_var, params.H)
+    _done(Y, params, SSTEP_A, diag_var, full_cov)
 
 
 def dual_updateB_(Y, params, diag_var=False):
@@ -688,10 +689,9 @@ def dual_updateCA_and_priors_(params, Y=None):
 def vbmf_dual_(Y, params, niter, eps=1e-6, diag_var=False, full_cov=False, logdir="", desc="", verb=False, est_priors=True,
                est_cb=True, log_every=1):
     """vbmf_dual! -- src/vbmf_dual.jl:455-530.  Returns d (like the reference).  logdir: see vbmf_."""
-    if full_cov:
-        raise NotImplementedError("only full_cov=false is built")
+    _check_full_cov(full_cov, diag_var, params.H)
     c = _sparse_ctx(Y, params, diag_var, dual=True)
-    _dpush(c, params, diag_var)
+    _dpush(c, params, diag_var, full_cov)
     iters, d = 0, eps + 1.0
     if logdir != "":
         logVar = create_log(params)
@@ -845,10 +845,12 @@ def vbmf_trial_init(Y, H, H0, M0, ca=1.0, alpha0=1e-10, beta0=1e-10, cb=1.0, gam
     return p
 
 
-def _tpush(c, p, diag_var=False):
+def _tpush(c, p, diag_var=False, full_cov=False):
     hyper = dict(alpha0=p.alpha01, beta0=p.beta01, gamma0=p.gamma0, delta0=p.delta0, eta0=p.eta0, zeta0=p.zeta0)
     c.sparse_set_state(p.ATVecHat, p.diagSigmaATVec, p.CA, p.beta, p.BHat, p.SigmaB, p.CB, p.delta, p.sigmaHat, p.zeta, hyper)
     c.trial_set_priors(p.H0, p.M0, {k: getattr(p, k) for k in Context.TRIAL_KEYS})
+    if not diag_var:
+        _push_SigmaA(c, p, full_cov)
     if diag_var:
         c.sparse_set_noise_rows(p.sigmaVecHat, p.zetaVec, float(np.asarray(p.etaVec).reshape(-1)[0]))
 
@@ -862,7 +864,7 @@ def _tpull(c, p, diag_var=False):
     p.A1Hat, p.A2Hat, p.A3Hat = p.AHat[:, :p.H0].copy(), p.AHat[:p.M0, p.H0:].copy(), p.AHat[p.M0:, p.H0:].copy()
     p.CA1, p.CA2, p.CA3 = _trial_split(p.CA, p.M, p.H, p.H0, p.M0)
     p.beta1, p.beta2, p.beta3 = _trial_split(p.beta, p.M, p.H, p.H0, p.M0)
-    p.SigmaA = np.diag(s["SigmaA_diag"])
+    p.SigmaA = np.ascontiguousarray(c.sparse_get_SigmaA())
     p.BHat, p.SigmaB, p.CB, p.delta = s["BHat"], s["SigmaB"], s["CB"], s["delta"]
     if not diag_var:
         p.sigmaHat, p.zeta = s["sigmaHat"], s["zeta"]
@@ -872,18 +874,17 @@ def _tpull(c, p, diag_var=False):
     p.alpha = np.array([p.alpha1, p.alpha2, p.alpha3])
 
 
-def _tone(Y, p, which, diag_var=False):
+def _tone(Y, p, which, diag_var=False, full_cov=False):
     c = _sparse_ctx(Y, p, diag_var, trial=True)
-    _tpush(c, p, diag_var)
+    _tpush(c, p, diag_var, full_cov)
     c.sparse_step(which)
     _tpull(c, p, diag_var)
 
 
 def trial_updateA_(Y, params, full_cov=False, diag_var=False):
-    """updateA! -- src/vbmf_trial.jl:250-320 (diagonal branch)."""
-    if full_cov:
-        raise NotImplementedError("only full_cov=false is built")
-    _tone(Y, params, SSTEP_A, diag_var)
+    """updateA! -- src/vbmf_trial.jl:250-320 (full_cov=true, :252-277: per-column blocks, see sparse_updateA_)."""
+    _check_full_cov(full_cov, diag_var, params.H)
+    _tone(Y, params, SSTEP_A, diag_var, full_cov)
 
 
 def trial_updateB_(Y, params, diag_var=False):
@@ -914,10 +915,9 @@ def trial_updateCA_and_priors_(params, Y=None):
 def vbmf_trial_(Y, params, niter, eps=1e-6, diag_var=False, full_cov=False, logdir="", desc="", verb=False, est_priors=True,
                 est_cb=True, log_every=1):
     """vbmf_trial! -- src/vbmf_trial.jl:528-604.  Returns d (like the reference).  logdir: see vbmf_."""
-    if full_cov:
-        raise NotImplementedError("only full_cov=false is built")
+    _check_full_cov(full_cov, diag_var, params.H)
     c = _sparse_ctx(Y, params, diag_var, trial=True)
-    _tpush(c, params, diag_var)
+    _tpush(c, params, diag_var, full_cov)
     iters, d = 0, eps + 1.0
     if logdir != "":
         logVar = create_log(params)
@@ -967,11 +967,11 @@ def vbls_(Y, params, niter, diag_var=False, full_cov=False):
     """vbls! -- examples/mil_util.jl:179-203: solves Y = B A' + E for A with B (and SigmaB, CB) fixed: niter x
     (updateA!, updateCA!, updateSigma2! / updateSigma!), then updateYHat!; returns params.AHat.
     On the device Y'B is formed once per call (B is fixed), so the call reads Y once, not 2 x niter times."""
-    if full_cov and not isinstance(params, vbmf_sparse_parameters):
-        raise NotImplementedError("full_cov=true is built for the sparse model's calls only")
+    if full_cov:
+        _check_full_cov(full_cov, diag_var, params.H)
     if isinstance(params, vbmf_dual_parameters):                         # examples/mil_util.jl:190-193
         c = _sparse_ctx(Y, params, diag_var, dual=True)
-        _dpush(c, params, diag_var)
+        _dpush(c, params, diag_var, full_cov)
         c.sparse_run_fixed_basis(int(niter))
         _dpull(c, params, diag_var)
         _dpull_priors(c, params)
@@ -979,7 +979,7 @@ def vbls_(Y, params, niter, diag_var=False, full_cov=False):
         return params.AHat
     if isinstance(params, vbmf_trial_parameters):                        # examples/mil_util.jl:194-197
         c = _sparse_ctx(Y, params, diag_var, trial=True)
-        _tpush(c, params, diag_var)
+        _tpush(c, params, diag_var, full_cov)
         c.sparse_run_fixed_basis(int(niter))
         _tpull(c, params, diag_var)
         params.YHat = params.BHat @ params.AHat.T if params.L * params.M <= YHAT_AUTO_LIMIT else None
