@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--factor", default="auto", choices=["auto", "bf16", "bf16x2"])
     ap.add_argument("--splits", type=int, default=0, help="split-K of the Y'B pass (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--full-cov", action="store_true",
+                    help="cfg5 only: updateA! with full_cov=true (one H x H inverse per column of Y on the device; H <= 64)")
     ap.add_argument("--event-stride", type=int, default=4,
                     help="HIP events bracket every k-th launch of each pass inside the timed region (each timed launch "
                          "costs two event packets on the stream; 1 = every launch)")
@@ -158,6 +160,8 @@ def main():
         hyper = dict(alpha0=1e-10, beta0=1e-10, gamma0=1e-10, delta0=1e-10, eta0=1e-10, zeta0=1e-10)
         ctx.sparse_set_state(A0.reshape(M * H), np.ones(M * H), 0.1 * np.ones(M * H), 1e-10 * np.ones(M * H), B0, z,
                              0.1 * np.ones(H), 1e-10 * np.ones(H), 0.1, 1e-10, hyper)
+        if a.full_cov:
+            ctx.sparse_set_full_cov(True)
         run = lambda k: ctx.sparse_run(k, eps=0.0, est_cb=True)
     else:
         ctx.set_state(A0, B0, z, z, 0.1 * np.ones(H), 0.1 * np.ones(H), 0.1)
@@ -254,7 +258,7 @@ def main():
                                       "1-rank RCCL communicator, L_global = the share): per-rank compute only, no inter-GPU latency")
     if sparse:
         out["metric"] = "VB iterations/sec (vbmf_sparse!, diagonal branch)"
-        out["config"]["workload"] = out["config"]["workload"].replace("vbmf! sweep, est_covs=est_var=true", "vbmf_sparse! sweep (full_cov=false, diag_var=false, est_cb=true)")
+        out["config"]["workload"] = out["config"]["workload"].replace("vbmf! sweep, est_covs=est_var=true", f"vbmf_sparse! sweep (full_cov={'true' if a.full_cov else 'false'}, diag_var=false, est_cb=true)")
     if rank == 0 and not a.no_cpu_baseline and world == 1 and not sparse:
         out["cpu_baseline"] = cpu_baseline(ctx, L, M, H, a.cpu_rows, a.cpu_sweeps, 20170102)
     elif rank == 0:
