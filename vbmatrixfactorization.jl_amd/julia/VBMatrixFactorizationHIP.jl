@@ -12,7 +12,8 @@ module VBMatrixFactorizationHIP
 
 export vbmf_parameters, vbmf_init, vbmf, vbmf!, updateA!, updateB!, updateCA!, updateCB!, updateSigma2!, updateYHat!,
        vbls!, copy_vbmf_params, preprocess_device, vbmf_on!,
-       vbmf_sparse_parameters, vbmf_sparse_init, vbmf_sparse!, lowerBound
+       vbmf_sparse_parameters, vbmf_sparse_init, vbmf_sparse!, lowerBound,
+       vbmf_dual_parameters, vbmf_dual_init, vbmf_dual!
 
 const libvbmf = get(ENV, "VBMF_HIP_LIB", joinpath(@__DIR__, "..", "libvbmf_hip.so"))
 
@@ -233,7 +234,7 @@ function vbmf_on!(c::Ctx, params::vbmf_parameters, niter::Int; eps::Float64 = 1e
     return params
 end
 
-# ---- the ARD-sparse variant, src/vbmf_sparse.jl (full_cov = false; diag_var = false | true) ---------------
+# ---- the ARD-sparse variant, src/vbmf_sparse.jl (full_cov = false | true; diag_var = false | true) ------
 # Same field names as the reference's vbmf_sparse_parameters (src/vbmf_sparse.jl:47-90); the dense MH x MH
 # SigmaATVec / invSigmaATVec of the full_cov branch are not carried (they cannot exist at scale, :120,122).
 mutable struct vbmf_sparse_parameters
@@ -272,12 +273,12 @@ function vbmf_sparse_init(Y::Array{Float64,2}, H::Int; ca = 1.0, alpha0 = 1e-10,
 end
 
 const _scache = Dict{UInt,Ctx}()
-function sparse_ctx_for(Y::Array{Float64,2}, H::Int, diag_var::Bool)
-    key = hash((objectid(Y), size(Y), H, diag_var))
+function sparse_ctx_for(Y::Array{Float64,2}, H::Int, diag_var::Bool; variant::Int = diag_var ? 2 : 1)
+    key = hash((objectid(Y), size(Y), H, variant))
     haskey(_scache, key) && return _scache[key]
     L, M = size(Y)
     ydt = get(ENV, "VBMF_HIP_Y", "bf16") == "f32" ? VBMF_Y_F32 : VBMF_Y_BF16
-    opts = Ref(VbmfOpts(Int32(sizeof(VbmfOpts)), 0, ydt, 0, diag_var ? 2 : 1, 0xffffffff, 1, 0, 0, 0, 0, 0))   # variant
+    opts = Ref(VbmfOpts(Int32(sizeof(VbmfOpts)), 0, ydt, 0, variant, 0xffffffff, 1, 0, 0, 0, 0, 0))   # VBMF_VARIANT_*
     h = Ref{Ptr{Cvoid}}(C_NULL)
     chk(Ptr{Cvoid}(C_NULL), ccall((:vbmf_create, libvbmf), Cint, (Ref{Ptr{Cvoid}}, Int64, Int64, Int64, Ref{VbmfOpts}), h, L, M, H, opts))
     chk(h[], ccall((:vbmf_set_Y, libvbmf), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64), h[], Y, L))
@@ -295,6 +296,18 @@ function spush!(c::Ctx, p::vbmf_sparse_parameters, diag_var::Bool)
         lab0, length(lab0), p.H1))
     diag_var && chk(c.h, ccall((:vbmf_sparse_set_noise_rows, libvbmf), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Float64),
                                c.h, p.sigmaVecHat, p.zetaVec, p.etaVec[1]))
+end
+
+# full_cov = true (src/vbmf_sparse.jl:178-202): the dense MH x MH covariance is block diagonal, the device inverts the M
+# H x H blocks; SigmaA is a full matrix then and is handed over explicitly
+function set_full_cov!(c::Ctx, p, full_cov::Bool)
+    chk(c.h, ccall((:vbmf_sparse_set_full_cov, libvbmf), Cint, (Ptr{Cvoid}, Cint), c.h, full_cov))
+    full_cov && chk(c.h, ccall((:vbmf_sparse_set_SigmaA, libvbmf), Cint, (Ptr{Cvoid}, Ptr{Float64}), c.h, p.SigmaA))
+end
+function pull_SigmaA!(c::Ctx, p)
+    S = Array{Float64}(undef, p.H, p.H)
+    chk(c.h, ccall((:vbmf_sparse_get_SigmaA, libvbmf), Cint, (Ptr{Cvoid}, Ptr{Float64}), c.h, S))
+    p.SigmaA = S
 end
 
 function spull!(c::Ctx, p::vbmf_sparse_parameters, diag_var::Bool)
@@ -322,13 +335,15 @@ end
 "vbmf_sparse! -- src/vbmf_sparse.jl:344-410 (returns d, like the reference)"
 function vbmf_sparse!(Y::Array{Float64,2}, params::vbmf_sparse_parameters, niter::Int; eps::Float64 = 1e-6, diag_var::Bool = false,
                       full_cov::Bool = false, logdir = "", desc = "", verb = false, est_cb::Bool = true)
-    full_cov && error("only full_cov=false is built")
+    full_cov && (diag_var || params.H > 64) && error("full_cov=true is built for diag_var=false and H <= 64")
     logdir == "" || error("trajectory logging lives in the Python host (data_manip.py)")
     c = sparse_ctx_for(Y, params.H, diag_var); spush!(c, params, diag_var)
+    diag_var || set_full_cov!(c, params, full_cov)
     iters = Ref{Int64}(0); d = Ref{Float64}(0.0)
     chk(c.h, ccall((:vbmf_sparse_run, libvbmf), Cint, (Ptr{Cvoid}, Int64, Float64, Cint, Ref{Int64}, Ref{Float64}, Ptr{Float64}),
                    c.h, niter, eps, est_cb, iters, d, C_NULL))
     spull!(c, params, diag_var)
+    full_cov && pull_SigmaA!(c, params)
     params.L * params.M <= (1 << 24) && (params.YHat = params.BHat * params.AHat')            # :396
     verb && print("Factorization finished after ", iters[], " iterations, eps = ", d[], "\n")
     return d[]
@@ -340,6 +355,97 @@ function lowerBound(Y::Array{Float64,2}, params::vbmf_sparse_parameters)
     lb = Ref{Float64}(0.0)
     chk(c.h, ccall((:vbmf_sparse_lower_bound, libvbmf), Cint, (Ptr{Cvoid}, Cint, Ref{Float64}), c.h, 1, lb))
     return lb[]
+end
+
+# ---- the two-group variant, src/vbmf_dual.jl (the three-group one, src/vbmf_trial.jl, is bound the same way through
+# vbmf_trial_set_priors / vbmf_trial_get_priors / vbmf_trial_run with H0, M0 and nine scalars) --------------------------
+# Field names of the reference's vbmf_dual_parameters (src/vbmf_dual.jl:59-112) minus the dense MH x MH pair.
+mutable struct vbmf_dual_parameters
+    L::Int; M::Int; MH::Int; H::Int; H0::Int; H1::Int
+    AHat::Array{Float64,2}; ATVecHat::Array{Float64,1}; diagSigmaATVec::Array{Float64,1}; SigmaA::Array{Float64,2}
+    A0Hat::Array{Float64,2}; A1Hat::Array{Float64,2}
+    BHat::Array{Float64,2}; SigmaB::Array{Float64,2}
+    CA::Array{Float64,1}; alpha::Array{Float64,1}; beta::Array{Float64,1}
+    CA0::Array{Float64,1}; alpha00::Float64; beta00::Float64; alpha0::Float64; beta0::Array{Float64,1}
+    CA1::Array{Float64,1}; alpha01::Float64; beta01::Float64; alpha1::Float64; beta1::Array{Float64,1}
+    CB::Array{Float64,1}; gamma0::Float64; delta0::Float64; gamma::Float64; delta::Array{Float64,1}
+    sigmaHat::Float64; eta0::Float64; zeta0::Float64; eta::Float64; zeta::Float64
+    sigmaVecHat::Array{Float64,1}; etaVec::Array{Float64,1}; zetaVec::Array{Float64,1}
+    YHat::Array{Float64,2}; trYTY::Float64
+    vbmf_dual_parameters() = new()
+end
+
+# (m, h)-interleaved vector <-> the two per-group vectors of src/vbmf_dual.jl:146-165
+dual_split(v, M, H, H0) = (a = reshape(v, H, M); (vec(a[1:H0, :]), vec(a[H0+1:end, :])))
+dual_join(v0, v1, M, H, H0) = vec(vcat(reshape(v0, H0, M), reshape(v1, H - H0, M)))
+
+"src/vbmf_dual.jl:122-193"
+function vbmf_dual_init(Y::Array{Float64,2}, H::Int, H0::Int; ca = 1.0, alpha0 = 1e-10, beta0 = 1e-10, cb = 1.0, gamma0 = 1e-10,
+                        delta0 = 1e-10, sigma = 1.0, eta0 = 1e-10, zeta0 = 1e-10)
+    H < H0 && error("H must be at least H0!")
+    p = vbmf_dual_parameters(); L, M = size(Y); H1 = H - H0
+    p.L, p.M, p.H, p.MH, p.H0, p.H1 = L, M, H, M * H, H0, H1
+    p.AHat = randn(M, H); p.ATVecHat = reshape(permutedims(p.AHat), M * H); p.diagSigmaATVec = ones(M * H); p.SigmaA = zeros(H, H)
+    p.A0Hat, p.A1Hat = p.AHat[:, 1:H0], p.AHat[:, H0+1:end]
+    p.BHat = randn(L, H); p.SigmaB = zeros(H, H)
+    p.CA0, p.CA1 = ca * ones(M * H0), ca * ones(M * H1); p.CA = dual_join(p.CA0, p.CA1, M, H, H0)
+    p.alpha00 = p.alpha01 = alpha0; p.beta00 = p.beta01 = beta0; p.alpha0 = p.alpha1 = alpha0 + 0.5
+    p.beta0, p.beta1 = beta0 * ones(M * H0), beta0 * ones(M * H1)
+    p.alpha = [p.alpha0, p.alpha1]; p.beta = dual_join(p.beta0, p.beta1, M, H, H0)
+    p.CB = cb * ones(H); p.gamma0, p.delta0, p.gamma, p.delta = gamma0, delta0, gamma0 + L / 2, delta0 * ones(H)
+    p.sigmaHat, p.eta0, p.zeta0, p.eta, p.zeta = sigma, eta0, zeta0, eta0 + L * M / 2, zeta0
+    p.sigmaVecHat, p.etaVec, p.zetaVec = sigma * ones(L), (eta0 + M / 2) * ones(L), zeta0 * ones(L)
+    p.YHat = L * M <= (1 << 24) ? p.BHat * p.AHat' : Array{Float64}(undef, 0, 0)
+    p.trYTY = sum(abs2, Y)
+    return p
+end
+
+"vbmf_dual! -- src/vbmf_dual.jl:455-530 (returns d); est_priors: the hyper-prior fits of :393-434 run on the device"
+function vbmf_dual!(Y::Array{Float64,2}, p::vbmf_dual_parameters, niter::Int; eps::Float64 = 1e-6, diag_var::Bool = false,
+                    full_cov::Bool = false, logdir = "", desc = "", verb = false, est_priors = true, est_cb::Bool = true)
+    full_cov && (diag_var || p.H > 64) && error("full_cov=true is built for diag_var=false and H <= 64")
+    logdir == "" || error("trajectory logging lives in the Python host (data_manip.py)")
+    c = sparse_ctx_for(Y, p.H, diag_var; variant = diag_var ? 5 : 3)          # VBMF_VARIANT_DUAL_DIAGVAR / _DUAL_DIAG
+    hy = Ref(SparseHyper(p.alpha00, p.beta00, p.gamma0, p.delta0, p.eta0, p.zeta0))
+    chk(c.h, ccall((:vbmf_sparse_set_state, libvbmf), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64},
+         Ptr{Float64}, Float64, Float64, Ref{SparseHyper}, Ptr{Int64}, Int64, Int64),
+        c.h, p.ATVecHat, p.diagSigmaATVec, p.CA, p.beta, p.BHat, p.L, p.SigmaB, p.CB, p.delta, p.sigmaHat, p.zeta, hy,
+        C_NULL, 0, 0))
+    chk(c.h, ccall((:vbmf_dual_set_priors, libvbmf), Cint, (Ptr{Cvoid}, Int64, Float64, Float64, Float64, Float64, Float64, Float64),
+                   c.h, p.H0, p.alpha00, p.beta00, p.alpha01, p.beta01, p.alpha0, p.alpha1))
+    diag_var ? chk(c.h, ccall((:vbmf_sparse_set_noise_rows, libvbmf), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Float64),
+                              c.h, p.sigmaVecHat, p.zetaVec, p.etaVec[1])) : set_full_cov!(c, p, full_cov)
+    iters = Ref{Int64}(0); d = Ref{Float64}(0.0)
+    chk(c.h, ccall((:vbmf_dual_run, libvbmf), Cint, (Ptr{Cvoid}, Int64, Float64, Cint, Cint, Ref{Int64}, Ref{Float64}, Ptr{Float64}),
+                   c.h, niter, eps, est_cb, est_priors, iters, d, C_NULL))
+    n = p.M * p.H
+    a = Array{Float64}(undef, n); ds = similar(a); ca = similar(a); be = similar(a); sa = Array{Float64}(undef, p.H)
+    B = Array{Float64}(undef, p.L, p.H); SB = Array{Float64}(undef, p.H, p.H); cb = Array{Float64}(undef, p.H); dl = similar(cb)
+    sh = Ref{Float64}(0.0); ze = Ref{Float64}(0.0)
+    chk(c.h, ccall((:vbmf_sparse_get_state, libvbmf), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Float64},
+         Ptr{Float64}, Ptr{Float64}, Ref{Float64}, Ref{Float64}),
+        c.h, a, ds, ca, be, sa, B, p.L, SB, cb, dl, sh, ze))
+    p.ATVecHat, p.diagSigmaATVec, p.CA, p.beta = a, ds, ca, be
+    p.AHat = permutedims(reshape(a, p.H, p.M)); p.A0Hat, p.A1Hat = p.AHat[:, 1:p.H0], p.AHat[:, p.H0+1:end]
+    p.CA0, p.CA1 = dual_split(ca, p.M, p.H, p.H0); p.beta0, p.beta1 = dual_split(be, p.M, p.H, p.H0)
+    pull_SigmaA!(c, p)
+    p.BHat, p.SigmaB, p.CB, p.delta = B, SB, cb, dl
+    if diag_var
+        s = Array{Float64}(undef, p.L); z = similar(s)
+        chk(c.h, ccall((:vbmf_sparse_get_noise_rows, libvbmf), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), c.h, s, z))
+        p.sigmaVecHat, p.zetaVec = s, z
+    else
+        p.sigmaHat, p.zeta = sh[], ze[]
+    end
+    H0r = Ref{Int64}(0); pr = Array{Float64}(undef, 6)
+    chk(c.h, ccall((:vbmf_dual_get_priors, libvbmf), Cint, (Ptr{Cvoid}, Ref{Int64}, Ptr{Float64}), c.h, H0r, pr))
+    p.alpha00, p.beta00, p.alpha01, p.beta01, p.alpha0, p.alpha1 = pr
+    p.alpha = [p.alpha0, p.alpha1]
+    p.L * p.M <= (1 << 24) && (p.YHat = p.BHat * p.AHat')                                       # :516
+    verb && print("Factorization finished after ", iters[], " iterations, eps = ", d[], "\n")
+    return d[]
 end
 
 end # module
