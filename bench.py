@@ -192,6 +192,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    chain = None if sparse else ctx.chain_us()
     s = {"sigma2": ctx.sparse_get_state(want_B=False)["sigmaHat"]} if sparse else ctx.get_state(want_B=False)
     bytes1, bytes2 = ctx.pass_bytes(1), ctx.pass_bytes(2)
     n = prof["pass1_n"] + prof["pass2_n"]
@@ -246,6 +247,7 @@ def main():
                       "GBps": bytes2 / max(prof["pass2_ms"] / max(prof["pass2_n"], 1), 1e-9) / 1e6},
         },
         "final": {"sigma2": s["sigma2"], "d": d},
+        "control_chain_us": chain,
     }
     out["roofline"]["other_roof"] = {"bound": "mfma", "achieved": mfma_achieved, "peak": mfma_peak, "unit": "TFLOP/s",
                                      "frac": mfma_achieved / mfma_peak, "flops_per_launch": flops}

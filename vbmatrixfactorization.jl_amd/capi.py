@@ -33,7 +33,7 @@ SYMBOLS = [
     "vbmf_sparse_set_full_cov", "vbmf_sparse_set_SigmaA", "vbmf_sparse_get_SigmaA",
 ]
 SSTEP_A, SSTEP_B, SSTEP_CA, SSTEP_CB, SSTEP_SIGMA, SSTEP_PRIORS = 1, 2, 4, 8, 16, 32
-PEEK_P, PEEK_Q, PEEK_A32, PEEK_B32, PEEK_FA, PEEK_FB, PEEK_Y1, PEEK_Y2, PEEK_DIMS = range(9)
+PEEK_P, PEEK_Q, PEEK_A32, PEEK_B32, PEEK_FA, PEEK_FB, PEEK_Y1, PEEK_Y2, PEEK_DIMS, PEEK_CHAIN = range(10)
 
 
 class VbmfOpts(C.Structure):
@@ -443,6 +443,11 @@ class Context:
         out = np.zeros(nwords, dtype=np.uint32)
         self._chk(self._lib.vbmf_debug_peek(self._h, what, out.ctypes.data_as(C.POINTER(C.c_uint32)), nwords, offset))
         return out.view(dtype)
+
+    def chain_us(self):
+        """Last durations (microseconds) of the in-launch control chain's parts."""
+        v = self.peek(PEEK_CHAIN, 8, dtype=np.uint64)
+        return dict(zip(("ctrl_end", "SigmaA", "lambda_max_dB_and_loop", "SigmaB"), (float(x) * 0.01 for x in v)))
 
     def dims(self):
         v = self.peek(PEEK_DIMS, 16, dtype=np.int32)

@@ -392,9 +392,10 @@ __global__ __launch_bounds__(T * T) void ctrl_cov_kernel(double* __restrict__ st
 // to the dominant eigenprojector; its largest-diagonal column is then polished by two fp64 power
 // steps on the ORIGINAL matrix and lambda = Rayleigh quotient in fp64.  The quotient's error is
 // quadratic in the vector's error; the worst case over all spectra is <= n/(2e*2^(NSQ+1)) relative
-// (~1e-4 at NSQ = 14, n = 64) and ~1e-12 whenever the top gap exceeds 0.1 %.  A cyclic Jacobi solve
+// (~2e-3 at NSQ = 10, n = 64; (1 - r) r^(2^(NSQ+1)) <= 1/(2e 2^NSQ) = 1.8e-4 for two competing eigenvalues of ratio r)
+// and ~1e-12 whenever the top gap exceeds 0.5 %.  A cyclic Jacobi solve
 // of the same matrix measured 2.9 ms on one CU; this is a few tens of microseconds.
-constexpr int EIG_NSQ = 14;
+constexpr int EIG_NSQ = 10;
 
 // which = 0: GD -> S_LAMD, 1: GB -> S_LAMB_NEW.  256 threads, 2*NP*(NP+4) floats of LDS (NP = 16R).
 template <int R>
@@ -461,7 +462,8 @@ __device__ __forceinline__ void eig_dev(double* __restrict__ st, StateLayout lay
             for (int b = 0; b < R; ++b) nxt[(ty + T * a) * LD + tx + T * b] = c[a][b] * sc;
         __syncthreads();
         float* tmp = cur; cur = nxt; nxt = tmp;
-        if (sq > 0 && fabs(ss - 1.0) < 1e-7) break;          // uniform: converged to the dominant projector
+        if (sq > 0 && fabs(ss - 1.0) < 1e-5) break;          // uniform: converged to the dominant projector (the fp64
+                                                             // Rayleigh quotient below squares what is left of the error)
     }
     // dominant column = the one with the largest diagonal entry of the (near) projector
     if (threadIdx.x < 64) {
@@ -586,8 +588,12 @@ __global__ __launch_bounds__(1024) void eig_power_kernel(double* __restrict__ st
 __device__ __forceinline__ void ctrl_end_dev(double* __restrict__ st, StateLayout lay, int H, double Lg, double M,
                                              int flags, double eps, double* __restrict__ trace,
                                              int* __restrict__ ints, int it_row = -1) {
+    // Inside a pass launch every dependent round trip to memory costs microseconds (the chip is streaming at full HBM
+    // bandwidth around this workgroup), so everything the function needs is requested up front in ONE round -- the stop
+    // flag, the scalars, the old CA/CB, the H x H arrays -- and the later stages work from registers and LDS.
     __shared__ double red[16];
-    if (load_stop(ints)) return;
+    __shared__ double sc_s[32];
+    __shared__ double dg[4][256];                                // diagonals of GA, SA, GB, SB
     const int Hp = lay.Hp;
     const double* GA = st + lay.GA();
     const double* GB = st + lay.GB();
@@ -597,38 +603,58 @@ __device__ __forceinline__ void ctrl_end_dev(double* __restrict__ st, StateLayou
     double* ca = st + lay.ca();
     double* cb = st + lay.cb();
     double* scal = st + lay.scal();
+    const int stopped = load_stop(ints);
+    const int hme = threadIdx.x;                                 // H <= 256 <= blockDim.x: one diagonal entry per thread
+    const double scv = hme < 32 ? scal[hme] : 0.0;
+    double ca_h = hme < H ? ca[hme] : 1.0, cb_h = hme < H ? cb[hme] : 1.0;
 
-    // tr(Y'BA') and tr((A'A + M SigmaA)(B'B + L SigmaB))
+    // tr(Y'BA') and tr((A'A + M SigmaA)(B'B + L SigmaB)); 8 elements per thread and round, all loads before the first use
     double t1 = 0.0, t2 = 0.0;
-    for (int t = threadIdx.x; t < H * H; t += blockDim.x) {
-        const int i = t / H, j = t - i * H;
-        const long long ij = (long long)i * Hp + j;
-        t1 += KB[ij] * GB[ij];
-        t2 += (GA[ij] + M * SA[ij]) * (GB[ij] + Lg * SB[ij]);
+    {
+        constexpr int U = 8;
+        const int sh = 31 - __clz(Hp), total = Hp * Hp;          // Hp is a power of two
+        for (int e0 = threadIdx.x; e0 < total; e0 += U * blockDim.x) {
+            double kb[U], gb[U], ga[U], sa[U], sb[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = e0 + u * blockDim.x;
+                const bool ok = e < total && (e >> sh) < H && (e & (Hp - 1)) < H;
+                const int ee = ok ? e : 0;
+                kb[u] = KB[ee]; gb[u] = GB[ee]; ga[u] = GA[ee]; sa[u] = SA[ee]; sb[u] = SB[ee];
+                if (!ok) { kb[u] = 0.0; ga[u] = 0.0; sa[u] = 0.0; }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = e0 + u * blockDim.x;
+                const int i = e >> sh, j = e & (Hp - 1);
+                if (e < total && i == j && i < H) { dg[0][i] = ga[u]; dg[1][i] = sa[u]; dg[2][i] = gb[u]; dg[3][i] = sb[u]; }
+                t1 += kb[u] * gb[u];
+                t2 += (ga[u] + M * sa[u]) * (gb[u] + Lg * sb[u]);
+            }
+        }
     }
-    t1 = block_sum(t1, red);
+    if (stopped) return;                                         // uniform
+    if (hme < 32) sc_s[hme] = scv;
+    t1 = block_sum(t1, red);                                     // (its barriers publish sc_s and dg)
     t2 = block_sum(t2, red);
-    const double trYBA = (flags & 16) ? t1 : scal[S_TRDOT];
-    const double resid = scal[S_TRYY] - 2.0 * trYBA + t2;
-    __syncthreads();
-    if (flags & 1) for (int h = threadIdx.x; h < H; h += blockDim.x) ca[h] = GA[(long long)h * Hp + h] / M + SA[(long long)h * Hp + h];
-    if (flags & 2) for (int h = threadIdx.x; h < H; h += blockDim.x) cb[h] = GB[(long long)h * Hp + h] / Lg + SB[(long long)h * Hp + h];
-    __syncthreads();
-    double sigma2 = scal[S_SIGMA2];
-    if (flags & 4) sigma2 = resid / (Lg * M);
-
-    // build-defined ELBO, with the post-update CA, CB, sigma2
+    const double trYBA = (flags & 16) ? t1 : sc_s[S_TRDOT];
+    const double resid = sc_s[S_TRYY] - 2.0 * trYBA + t2;
     double e = 0.0;
-    for (int h = threadIdx.x; h < H; h += blockDim.x) {
-        const long long hh = (long long)h * Hp + h;
-        e += -(M / 2.0) * log(ca[h]) - 0.5 * (GA[hh] + M * SA[hh]) / ca[h];
-        e += -(Lg / 2.0) * log(cb[h]) - 0.5 * (GB[hh] + Lg * SB[hh]) / cb[h];
+    if (hme < H) {
+        const double gaa = dg[0][hme], saa = dg[1][hme], gbb = dg[2][hme], sbb = dg[3][hme];
+        if (flags & 1) { ca_h = gaa / M + saa; ca[hme] = ca_h; }
+        if (flags & 2) { cb_h = gbb / Lg + sbb; cb[hme] = cb_h; }
+        // build-defined ELBO, with the post-update CA, CB, sigma2
+        e += -(M / 2.0) * log(ca_h) - 0.5 * (gaa + M * saa) / ca_h;
+        e += -(Lg / 2.0) * log(cb_h) - 0.5 * (gbb + Lg * sbb) / cb_h;
     }
+    double sigma2 = sc_s[S_SIGMA2];
+    if (flags & 4) sigma2 = resid / (Lg * M);
     e = block_sum(e, red);
     if (threadIdx.x == 0) {
         const double PI2 = 6.283185307179586476925286766559;
         double F = -(Lg * M / 2.0) * log(PI2 * sigma2) - resid / (2.0 * sigma2) + e;
-        F += (M / 2.0) * scal[S_LOGDET_SA] + M * H / 2.0 + (Lg / 2.0) * scal[S_LOGDET_SB] + Lg * H / 2.0;
+        F += (M / 2.0) * sc_s[S_LOGDET_SA] + M * H / 2.0 + (Lg / 2.0) * sc_s[S_LOGDET_SB] + Lg * H / 2.0;
         scal[S_SIGMA2] = sigma2;
         scal[S_ELBO] = F;
         scal[S_RESID] = resid;
@@ -636,9 +662,9 @@ __device__ __forceinline__ void ctrl_end_dev(double* __restrict__ st, StateLayou
         if (flags & 64) {
             if (trace) { trace[4 * it_row + 1] = sigma2; trace[4 * it_row + 2] = F; trace[4 * it_row + 3] = resid; }
         } else if (flags & 8) {
-            const double d = sqrt(scal[S_LAMD] / scal[S_LAMB_PREV]);
+            const double d = sqrt(sc_s[S_LAMD] / sc_s[S_LAMB_PREV]);
             scal[S_D] = d;
-            if (!(flags & 32)) scal[S_LAMB_PREV] = scal[S_LAMB_NEW];   // (32: lambda_max of the old B is written there directly)
+            if (!(flags & 32)) scal[S_LAMB_PREV] = sc_s[S_LAMB_NEW];   // (32: lambda_max of the old B is written there directly)
             const int it = ints[I_ITERS];
             if (trace) { trace[4 * it + 0] = d; trace[4 * it + 1] = sigma2; trace[4 * it + 2] = F; trace[4 * it + 3] = resid; }
             ints[I_ITERS] = it + 1;
@@ -646,7 +672,9 @@ __device__ __forceinline__ void ctrl_end_dev(double* __restrict__ st, StateLayou
                 __hip_atomic_store(ints + I_STOP, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    __threadfence();
+    // (no device-scope fence here: the consumers are later kernels -- the launch boundary publishes these stores -- or this
+    //  same workgroup after the barrier; on gfx950 an agent-scope release writes back the XCD's whole L2, which costs
+    //  several microseconds inside a pass that is filling that L2 with its own output)
     __syncthreads();
 }
 
@@ -689,7 +717,7 @@ __device__ __forceinline__ void ctrl_loop_dev(double* __restrict__ st, StateLayo
         if (!(d > eps) || it_row + 1 >= ints[I_NITER])                      // NaN d exits too
             __hip_atomic_store(ints + I_STOP, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __threadfence();
+    // (see ctrl_end_dev: no device-scope fence; the stop flag itself is an agent-scope atomic)
     __syncthreads();
 }
 
@@ -700,14 +728,25 @@ __device__ __forceinline__ void ctrl_loop_dev(double* __restrict__ st, StateLayo
 //   part 1:  lambda_max(dB'dB) -> d, trace, iteration count, stop                    |  lambda_max(B_old'B_old)
 // Part 1's stop decision does not wait for part 0 and vice versa; CA/CB/sigma2 belong to the finished sweep and are
 // due whether or not the loop stops, SigmaA belongs to the next one and is not.
+// Durations of the chain's parts in 10 ns ticks of the constant 100 MHz clock, kept in ints[8..15] as four 64-bit slots
+// (vbmf_debug_peek(VBMF_PEEK_CHAIN)): [0] ctrl_end, [1] SigmaA, [2] lambda_max(dB'dB) + loop test, [3] SigmaB
 template <int R>
 __device__ __forceinline__ void ctrl_chain(const CtrlArgs& a, void* lds, int part) {
+    unsigned long long* stamp = reinterpret_cast<unsigned long long*>(a.ints + 8);
+    const unsigned long long t0 = wall_clock64();
     if (part == 0) {
         if (a.mode & CTRL_PREV_END)
             ctrl_end_dev(a.st, a.lay, a.H, a.Lg, a.M, (a.end_flags & ~8) | 64, a.eps, a.trace, a.ints, a.it_row);
+        const unsigned long long t1 = wall_clock64();
         if (a.mode & CTRL_COV_A)
             ctrl_cov_dev<R, 16>(a.st, a.lay, a.H, 0, a.Lg, a.S32, a.ints, reinterpret_cast<double*>(lds), true);
         if (a.mode & CTRL_COV_B) ctrl_cov_dev<R, 16>(a.st, a.lay, a.H, 1, a.M, a.S32, a.ints, reinterpret_cast<double*>(lds));
+        if (threadIdx.x == 0) {
+            const unsigned long long t2 = wall_clock64();
+            if (a.mode & CTRL_PREV_END) stamp[0] = t1 - t0;
+            if (a.mode & CTRL_COV_A) stamp[1] = t2 - t1;
+            if (a.mode & CTRL_COV_B) stamp[3] = t2 - t1;
+        }
         if (a.sready) {                                     // set unconditionally: a waiting epilogue must never hang
             __threadfence();
             __syncthreads();
@@ -717,6 +756,7 @@ __device__ __forceinline__ void ctrl_chain(const CtrlArgs& a, void* lds, int par
         if (a.mode & CTRL_PREV_END) {
             eig_dev<R>(a.st, a.lay, a.H, a.spectral, 0, a.ints, reinterpret_cast<float*>(lds), S_LAMD);
             ctrl_loop_dev(a.st, a.lay, a.eps, a.trace, a.ints, a.it_row);
+            if (threadIdx.x == 0) stamp[2] = wall_clock64() - t0;
         }
         if (a.mode & CTRL_EIG_BOLD)
             eig_dev<R>(a.st, a.lay, a.H, a.spectral, 1, a.ints, reinterpret_cast<float*>(lds), S_LAMB_PREV);

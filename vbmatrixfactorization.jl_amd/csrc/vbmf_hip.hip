@@ -943,7 +943,7 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
         hipEventCreateWithFlags(&c->ev_chk[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_chk[1], hipEventDisableTiming) != hipSuccess) { c->err = "side stream create failed"; return bail(VBMF_ERR_HIP); }
     // large dynamic LDS (160 KiB per CU on gfx950) for the lambda_max kernel at 64 < H <= 128
-    c->lds_limit = 160 * 1024 - 4096;
+    c->lds_limit = 160 * 1024 - 16384;         // leaves room for the kernels' static LDS (ctrl_end's tables: 8.4 KB)
     {
         hipError_t e = hipFuncSetAttribute((const void*)eig_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
         if (e == hipSuccess && c->NH == 4) {
@@ -1550,6 +1550,11 @@ int vbmf_debug_peek(vbmf_ctx* c, int what, uint32_t* out, int64_t nwords, int64_
         const int v[16] = {c->Hp, c->NH, c->mode, c->d1.XT, c->d1.KS, c->d1.nsplit, c->d1.steps_per_split,
                            c->d2.XT, c->d2.KS, c->d2.nsplit, c->d2.steps_per_split, c->kstep, c->npart, 0, 0, 0};
         memcpy(out, v, sizeof(int) * (size_t)std::min<int64_t>(16, nwords));
+        return VBMF_OK;
+    }
+    if (what == VBMF_PEEK_CHAIN) {
+        if (nwords > 8) FAIL(c, VBMF_ERR_INVALID, "vbmf_debug_peek: the chain stamps are 8 words");
+        HIPCHK(c, hipMemcpy(out, c->ints + 8, (size_t)nwords * 4, hipMemcpyDeviceToHost));
         return VBMF_OK;
     }
     const void* base = nullptr;
