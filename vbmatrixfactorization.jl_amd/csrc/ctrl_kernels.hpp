@@ -155,6 +155,67 @@ __device__ __forceinline__ void gj_tiled(double (&w)[R][R], int n, double* strip
     }
 }
 
+// The same sweep on NB independent matrices at once (same n): one barrier per pivot serves all of them and their
+// dependent LDS round trips overlap.
+// strip: NB * 4*T*R doubles, pivs: NB * T*R doubles (matrix q's pivots at pivs + q*T*R).
+template <int R, int T, int NB>
+__device__ __forceinline__ void gj_tiled_n(double (&w)[NB][R][R], int n, double* strip, double* pivs) {
+    const int tx = threadIdx.x % T, ty = threadIdx.x / T;
+    constexpr int NP = T * R;
+    double pinv_next[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) pinv_next[q] = fast_rcp(w[q][0][0]);
+#pragma unroll
+    for (int a0 = 0; a0 < R; ++a0) {
+        for (int t = 0; t < T; ++t) {
+            const int k = a0 * T + t;
+            if (k >= n) break;                                  // uniform
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                double* row = strip + q * (4 * NP) + (k & 1) * (2 * NP);
+                double* col = row + NP;
+                if (ty == t) {
+#pragma unroll
+                    for (int b = 0; b < R; ++b) row[tx + T * b] = w[q][a0][b];
+                }
+                if (tx == t) {
+#pragma unroll
+                    for (int a = 0; a < R; ++a) col[ty + T * a] = (a == a0 && ty == t) ? pinv_next[q] : w[q][a][a0];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                const double* row = strip + q * (4 * NP) + (k & 1) * (2 * NP);
+                const double* col = row + NP;
+                const double piv = row[k];
+                const double pinv = col[k];
+                if (threadIdx.x == 0) pivs[q * NP + k] = piv;
+                double ci[R], rj[R];
+#pragma unroll
+                for (int a = 0; a < R; ++a) ci[a] = col[ty + T * a];
+#pragma unroll
+                for (int b = 0; b < R; ++b) rj[b] = row[tx + T * b] * pinv;
+#pragma unroll
+                for (int a = 0; a < R; ++a) {
+                    const bool is_i = (a == a0) && (ty == t);
+#pragma unroll
+                    for (int b = 0; b < R; ++b) {
+                        const bool is_j = (b == a0) && (tx == t);
+                        const double upd = w[q][a][b] - ci[a] * rj[b];
+                        const double on_row = is_j ? pinv : rj[b];
+                        const double on_col = -ci[a] * pinv;
+                        w[q][a][b] = is_i ? on_row : (is_j ? on_col : upd);
+                    }
+                }
+                double cand = w[q][a0][a0];
+                if (a0 + 1 < R) cand = (t + 1 < T) ? cand : w[q][a0 + 1][a0 + 1];
+                pinv_next[q] = fast_rcp(cand);
+            }
+        }
+    }
+}
+
 // ---- 129 <= H <= 256: blocked inverse -----------------------------------------------------------
 // A 256 x 256 fp64 matrix is 512 KB -- the whole register file of a CU -- so the register-tiled sweep
 // above cannot hold it (its 8 x 8 tiles at 1024 threads spill: measured 2.4 ms).  Split K = [A B; B' D] into

@@ -70,6 +70,9 @@ __global__ __launch_bounds__(256) void sparse_update_a_kernel(const float* __res
 // SigmaA = sum_m Sigma_m  (a full H x H matrix here) -- the per-column posterior update with the small covariance
 // inverted in LDS/registers by one workgroup per column (gj_tiled).  The dense matrix is never formed.
 // Block b walks columns m = b, b + grid, ...; its sum of Sigma_m goes to part[b] (folded in fixed order afterwards).
+// Two columns per round and workgroup (gj_tiled_n<R, T, 2>, one barrier per pivot for both).  Measured: only +2.5 % over one
+// column per round -- with two workgroups per CU the sweep is bound by instruction issue (~70 instructions per pivot step and
+// wave), not by the LDS round trips; an fp64-MFMA rank-4 update per 16 x 16 tile is what would change that.
 template <int R, int T>
 __global__ __launch_bounds__(T * T) void sparse_update_a_full_kernel(const float* __restrict__ P, long long ldP,
                                                                      const float* __restrict__ CA32,
@@ -80,11 +83,11 @@ __global__ __launch_bounds__(T * T) void sparse_update_a_full_kernel(const float
                                                                      double* __restrict__ part, int* __restrict__ ints) {
     extern __shared__ __attribute__((aligned(16))) double lds_full[];
     if (load_stop(ints)) return;
-    constexpr int NP = T * R;
+    constexpr int NP = T * R, NB = 2;
     const int tx = threadIdx.x % T, ty = threadIdx.x / T;
-    double* strip = lds_full;                 // 4 * NP
-    double* pivs = lds_full + 4 * NP;         // NP
-    double* pv = lds_full + 5 * NP;           // NP: (B'Y)[:, m]
+    double* strip = lds_full;                      // NB * 4 * NP
+    double* pivs = lds_full + NB * 4 * NP;         // NB * NP
+    double* pv = lds_full + NB * 5 * NP;           // NB * NP: (B'Y)[:, m] of the two columns
     const double sig = st[lay.scal() + S_SIGMA2];
     double k0[R][R], acc[R][R];
 #pragma unroll
@@ -96,43 +99,60 @@ __global__ __launch_bounds__(T * T) void sparse_update_a_full_kernel(const float
             acc[a][b] = 0.0;
         }
     int bad = 0;
-    for (long long m = blockIdx.x; m < M; m += gridDim.x) {
-        double w[R][R];
+    for (long long mb = blockIdx.x; mb < M; mb += (long long)NB * gridDim.x) {
+        long long mm[NB];
+        bool live[NB];
 #pragma unroll
-        for (int a = 0; a < R; ++a)
+        for (int q = 0; q < NB; ++q) { mm[q] = mb + (long long)q * gridDim.x; live[q] = mm[q] < M; if (!live[q]) mm[q] = mb; }
+        double w[NB][R][R];
 #pragma unroll
-            for (int b = 0; b < R; ++b) {
-                const int i = ty + T * a, j = tx + T * b;
-                double v = (i == j) ? 1.0 : 0.0;                        // identity padding
-                if (i < H && j < H) v = k0[a][b] + ((i == j) ? (double)CA32[m * Hp + i] : 0.0);
-                w[a][b] = v;
-            }
-        for (int h = threadIdx.x; h < NP; h += T * T) pv[h] = h < H ? (double)P[(long long)h * ldP + m] : 0.0;
-        gj_tiled<R, T>(w, H, strip, pivs);
+        for (int q = 0; q < NB; ++q)
+#pragma unroll
+            for (int a = 0; a < R; ++a)
+#pragma unroll
+                for (int b = 0; b < R; ++b) {
+                    const int i = ty + T * a, j = tx + T * b;
+                    double v = (i == j) ? 1.0 : 0.0;                    // identity padding
+                    if (i < H && j < H) v = k0[a][b] + ((i == j) ? (double)CA32[mm[q] * Hp + i] : 0.0);
+                    w[q][a][b] = v;
+                }
+        for (int h = threadIdx.x; h < NB * NP; h += T * T) {
+            const int q = h / NP, hh = h - q * NP;
+            pv[h] = hh < H ? (double)P[(long long)hh * ldP + mm[q]] : 0.0;
+        }
+        gj_tiled_n<R, T, NB>(w, H, strip, pivs);
         __syncthreads();                                                // pv and pivs complete
-        for (int k = threadIdx.x; k < H; k += T * T) { const double q = pivs[k]; if (!(q > 0.0) || !isfinite(q)) bad = 1; }
+        for (int k = threadIdx.x; k < NB * NP; k += T * T) {
+            const int q = k / NP, kk = k - q * NP;
+            if (kk < H) { const double pq = pivs[k]; if (!(pq > 0.0) || !isfinite(pq)) bad = 1; }
+        }
 #pragma unroll
-        for (int a = 0; a < R; ++a) {
-            const int i = ty + T * a;
-            double sm = 0.0;
+        for (int q = 0; q < NB; ++q) {
+            if (!live[q]) continue;                                     // uniform (a dummy copy of column mb when M runs out)
+            const long long m = mm[q];
 #pragma unroll
-            for (int b = 0; b < R; ++b) sm += w[a][b] * pv[tx + T * b];
-            for (int off = T / 2; off > 0; off >>= 1) sm += __shfl_xor(sm, off);       // the T lanes of a row are contiguous
-            if (tx == 0 && i < H) {
-                float av = (float)(sig * sm);
-                if (mask != nullptr && i >= hmask_start && mask[m]) av = 0.f;
-                A32[m * Hp + i] = av;
-            }
+            for (int a = 0; a < R; ++a) {
+                const int i = ty + T * a;
+                double sm = 0.0;
 #pragma unroll
-            for (int b = 0; b < R; ++b) {
-                const int j = tx + T * b;
-                if (i < H && j < H) {
-                    acc[a][b] += w[a][b];
-                    if (i == j) dS32[m * Hp + i] = (float)w[a][b];
+                for (int b = 0; b < R; ++b) sm += w[q][a][b] * pv[q * NP + tx + T * b];
+                for (int off = T / 2; off > 0; off >>= 1) sm += __shfl_xor(sm, off);   // the T lanes of a row are contiguous
+                if (tx == 0 && i < H) {
+                    float av = (float)(sig * sm);
+                    if (mask != nullptr && i >= hmask_start && mask[m]) av = 0.f;
+                    A32[m * Hp + i] = av;
+                }
+#pragma unroll
+                for (int b = 0; b < R; ++b) {
+                    const int j = tx + T * b;
+                    if (i < H && j < H) {
+                        acc[a][b] += w[q][a][b];
+                        if (i == j) dS32[m * Hp + i] = (float)w[q][a][b];
+                    }
                 }
             }
         }
-        __syncthreads();                                                // LDS is rewritten by the next column
+        __syncthreads();                                                // LDS is rewritten by the next round
     }
     if (bad) atomicExch(ints + I_ERR, 1);
 #pragma unroll

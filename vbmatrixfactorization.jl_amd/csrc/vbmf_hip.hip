@@ -1649,7 +1649,7 @@ static int sparse_colsum(vbmf_ctx* c) {
 
 template <int R, int T>
 static void launch_full_a_t(vbmf_ctx* c) {
-    hipLaunchKernelGGL((sparse_update_a_full_kernel<R, T>), dim3(c->fblocks), dim3(T * T), (size_t)(6 * T * R) * sizeof(double), c->stream,
+    hipLaunchKernelGGL((sparse_update_a_full_kernel<R, T>), dim3(c->fblocks), dim3(T * T), (size_t)(12 * T * R) * sizeof(double), c->stream,
                        c->Pred, (long long)c->d1.XT * 32, c->CA32, c->st, c->lay, c->A32, c->dS32, c->has_mask ? c->mask : nullptr,
                        (int)(c->H - c->H1), (long long)c->M, (int)c->H, c->Hp, (double)c->Lg, c->fpart, c->ints);
 }
@@ -2044,7 +2044,7 @@ int vbmf_sparse_set_full_cov(vbmf_ctx* c, int on) {
     if (on && c->H > 64) FAIL(c, VBMF_ERR_UNSUPPORTED, "full_cov is built for H <= 64");
     HIPCHK(c, hipSetDevice(c->o.device));
     if (on && !c->fpart) {
-        c->fblocks = (int)std::min<int64_t>(c->M, 1024);
+        c->fblocks = (int)std::max<int64_t>(1, std::min<int64_t>((c->M + 1) / 2, 1024));     // two columns per round and workgroup
         const size_t bytes = (size_t)c->fblocks * c->Hp * c->Hp * 8;
         HIPCHK(c, hipMalloc((void**)&c->fpart, bytes));
         HIPCHK(c, hipMemset(c->fpart, 0, bytes));
