@@ -210,3 +210,30 @@ def test_trial_full_cov_run(pkg):
     d_ref, n = O.vbmf_trial_(Yf, po, 10, eps=0.0, full_cov=True, est_priors=True)
     _cmp("full_cov run10 f32", pg, po, 2e-3, priors_tol=2e-3)
     assert np.any(pg.SigmaA != np.diag(np.diag(pg.SigmaA))) and abs(d_gpu - d_ref) <= 2e-2 * d_ref + 2e-6
+
+
+@pytest.mark.parametrize("L,M,H,H0,M0", [(37, 41, 1, 0, 13), (50, 33, 1, 1, 5), (65, 97, 17, 9, 96), (130, 70, 33, 32, 1),
+                                         (90, 129, 64, 31, 64)])
+def test_trial_odd_shapes_all_branches(pkg, L, M, H, H0, M0):
+    """Shapes off every tile boundary (H = 1, 17, 33, 64; M, M0 not multiples of 32; a one-row block): the grouped CA update
+    with prior fits, then updateA! through the diagonal AND the per-column full-covariance branch, against the oracle."""
+    Y, po = _mk(L, M, H, H0, M0, 900 + H)
+    pkg.set_defaults(y_dtype=pkg.VBMF_Y_F32, factor_dtype=pkg.VBMF_FACTOR_AUTO)
+    Yf = Y.astype(np.float32).astype(np.float64)
+    po.trYTY = float(np.sum(Yf * Yf))
+    tag = f"odd {L}x{M} H{H}/{H0} M0={M0}"
+    O.vbmf_trial_(Yf, po, 2, eps=0.0, est_priors=True)
+    pg = _to_pkg(pkg, po)
+    pkg.trial_updateCA_and_priors_(pg, Y=Yf); O.trial_updateCA(po); O.trial_updatePriors(po)
+    _cmp(f"{tag} updateCA+priors", pg, po, 5e-5, GROUPS, priors_tol=1e-5)
+    for full in (False, True):
+        qo = O.vbmf_trial_init(Yf, H, H0, M0, rng=np.random.default_rng(1), materialize_yhat=False)
+        for f in SCAL + ARRS:
+            v = getattr(po, f)
+            setattr(qo, f, v.copy() if isinstance(v, np.ndarray) else v)
+        pg = _to_pkg(pkg, qo)
+        pkg.trial_updateA_(Yf, pg, full_cov=full); O.trial_updateA(Yf, qo, full_cov=full)
+        _cmp(f"{tag} updateA full_cov={full}", pg, qo, 5e-5, ("ATVecHat", "diagSigmaATVec", "SigmaA", "A1Hat", "A2Hat", "A3Hat"))
+        pg = _to_pkg(pkg, qo)
+        pkg.trial_updateB_(Yf, pg); O.sparse_updateB(Yf, qo)
+        _cmp(f"{tag} updateB after full_cov={full}", pg, qo, 5e-5, ("BHat", "SigmaB"))
