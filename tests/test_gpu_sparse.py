@@ -312,5 +312,8 @@ def test_full_cov_against_the_oracle(pkg, L, M, H):
         pkg.vbmf_sparse_(Yf, pg, 6, eps=0.0, full_cov=True)
         O.vbmf_sparse_(Yf, po, 6, eps=0.0, full_cov=True)
         _cmp(f"full_cov {L}x{M} H{H} run6", pg, po, 1e-3)
+        lb_gpu, lb_ref = pkg.lowerBound(Yf, _to_pkg(pkg, po)), O.lowerBound(Yf, po)   # the bound of a full-SigmaA state
+        report(f"full_cov {L}x{M} H{H} lowerBound of the oracle's state: gpu {lb_gpu:.6f} oracle {lb_ref:.6f}")
+        assert abs(lb_gpu - lb_ref) <= 2e-5 * abs(lb_ref)
     with pytest.raises(NotImplementedError):
         pkg.sparse_updateA_(Yf, pg, full_cov=True, diag_var=True)
