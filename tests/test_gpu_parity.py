@@ -395,3 +395,22 @@ def test_rank_above_128_loop_and_termination(pkg):
     assert n == k + 2 and pg._last_run[0] == n
     compare("bf16x2 700x520 H130 run-to-stop", pg, po, {k_: 10 * v for k_, v in tol.items()})
     assert abs(pg._last_run[1] - d) <= 3e-2 * d + D_ATOL
+
+
+@pytest.mark.parametrize("geometry", ["wide", "narrow"])
+@pytest.mark.parametrize("mode,L,M,H", [("f32", 700, 420, 24), ("bf16x2", 777, 555, 64), ("bf16x2", 3000, 1300, 40)])
+def test_stream_geometry_forced(pkg, monkeypatch, geometry, mode, L, M, H):
+    """The streaming kernel has two tile geometries for H <= 64 (8/NH or 4/NH x tiles per wave); the planner picks the narrow
+    one only when the wide one would leave <= 2 column groups, so small test shapes would never run the wide kernels (and
+    large ones never the narrow).  Force each (VBMF_NARROW is read when a context is created; Ys is a fresh array, so the host
+    mirror opens a fresh session for it) and compare with the oracle."""
+    monkeypatch.setenv("VBMF_NARROW", "1" if geometry == "narrow" else "0")
+    Y, po = _problem(L, M, H, 500 + H)
+    ydt, fdt, tol = _mode_opts(pkg, mode)
+    Ys = _stored(pkg, Y, H, ydt, fdt)
+    pkg.set_defaults(y_dtype=ydt, factor_dtype=fdt)
+    pg = to_pkg_params(pkg, po)
+    pkg.vbmf_(Ys, pg, 3, eps=0.0, est_covs=True, est_var=True)
+    _, n, d = O.vbmf_(Ys, po, 3, eps=0.0, est_covs=True, est_var=True)
+    compare(f"{geometry} geometry {mode} {L}x{M} H{H} run3", pg, po, {k: 6 * v for k, v in tol.items()})
+    assert pg._last_run[0] == 3 and abs(pg._last_run[1] - d) <= 5e-3 * d + D_ATOL

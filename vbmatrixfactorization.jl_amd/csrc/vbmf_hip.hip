@@ -80,6 +80,7 @@ struct vbmf_ctx {
     int gpart_blocks = 0;
     // full_cov = true: block-diagonal posterior of vec(A') (one H x H inverse per column of Y)
     bool full_cov = false;
+    bool narrow = false;             // NarrowCfg geometry of the streaming kernel (small problems)
     double* fpart = nullptr;         // per-block sums of Sigma_m
     int fblocks = 0;
     vbmf_sparse_hyper hyp{};
@@ -190,8 +191,21 @@ template <> struct StreamCfg<2> { static constexpr int NXWc = 4; static constexp
 template <> struct StreamCfg<4> { static constexpr int NXWc = 4; static constexpr int DYc = 4; static constexpr int DFc = 2; static constexpr int Rc = 8; };
 template <> struct StreamCfg<8> { static constexpr int NXWc = 2; static constexpr int DYc = 2; static constexpr int DFc = 2; static constexpr int Rc = 0; };
 
-static int nxw_of(int NH) { return NH == 1 ? 8 : (NH == 8 ? 2 : 4); }              // = StreamCfg<NH>::NXWc
-static int dy_of(int NH) { return NH == 1 ? 3 : (NH == 2 ? 6 : (NH == 4 ? 4 : 2)); } // = StreamCfg<NH>::DYc
+// "narrow" geometry (H <= 64, small problems): half the x tiles per wave, so twice the column groups -- a 1000-column matrix
+// is ONE column group of the wide H <= 32 kernel (64 split-K workgroups on 256 CUs), and an 8-way row shard needs half the
+// split-K slices.  Costs factor-operand traffic per Y byte: chosen only when the wide geometry has <= 2 column groups.
+template <int NH> struct NarrowCfg;
+template <> struct NarrowCfg<1> { static constexpr int NXWc = 4; static constexpr int DYc = 6; static constexpr int DFc = 3; static constexpr int Rc = 2; };
+template <> struct NarrowCfg<2> { static constexpr int NXWc = 2; static constexpr int DYc = 12; static constexpr int DFc = 2; static constexpr int Rc = 4; };
+
+static int nxw_of(int NH, bool narrow = false) {                                     // = StreamCfg<NH>::NXWc / NarrowCfg<NH>::NXWc
+    if (narrow && NH <= 2) return NH == 1 ? 4 : 2;
+    return NH == 1 ? 8 : (NH == 8 ? 2 : 4);
+}
+static int dy_of(int NH, bool narrow = false) {                                      // = ...::DYc
+    if (narrow && NH <= 2) return NH == 1 ? 6 : 12;
+    return NH == 1 ? 3 : (NH == 2 ? 6 : (NH == 4 ? 4 : 2));
+}
 // two CUs are left to the control workgroups that ride in each pass launch
 constexpr int NUM_CU = 254;
 
@@ -200,13 +214,13 @@ constexpr int NUM_CU = 254;
 //     max( rounds * bytes_per_block / R_CU ,  total_bytes / R_HBM )  +  slab write+read
 // with rounds = ceil(blocks / 256).  Pick the split factor minimising that (measured at 100k x 10k:
 // 240 blocks 0.35 ms, 260 blocks 0.61 ms, 160 blocks 0.44 ms -- the model's ordering).
-static void plan_pass(Dims& d, int64_t X, int64_t K, int kstep, int NH, int Hp, double ybytes, int want_splits) {
+static void plan_pass(Dims& d, int64_t X, int64_t K, int kstep, int NH, int Hp, double ybytes, int want_splits, bool narrow) {
     // padding quanta: x tiles to the per-wave tile count, k-steps to the Y ring depth (zero tiles are streamed
     // like real ones, so padding is pure waste: 3.7 % of pass 2 at 100k x 10k with the old 8-tile / 12-step quanta)
-    const int xq = nxw_of(NH), kq = dy_of(NH);
+    const int xq = nxw_of(NH, narrow), kq = dy_of(NH, narrow);
     d.XT = (int)rup(cdiv(X, 32), xq);
     const int64_t ks_min = rup(cdiv(rup(K, 32 * xq), kstep), kq);   // K padded like the other pass's x tiles
-    const int XG = d.XT / nxw_of(NH);
+    const int XG = d.XT / xq;
     const int bps = (XG + 3) / 4;
     int ns = want_splits;
     if (ns <= 0) {
@@ -285,7 +299,7 @@ static int launch_stream(vbmf_ctx* c, int pass, int ctrl_mode = 0, bool epi = fa
     const uint4* F = pass == 0 ? (c->diagvar ? c->FBs : c->FB) : c->FA;
     float* out = pass == 0 ? c->P : c->Q;
     const long long ld = (long long)d.XT * 32;
-    const int XG = d.XT / nxw_of(c->NH);
+    const int XG = d.XT / nxw_of(c->NH, c->narrow);
     const int bps = (XG + 3) / 4;
     // split-K launches use the XCD-aware work map (stream_gemm.hpp): 8 * per workgroups, per = ceil(blocks / 8)
     const int xper = (d.nsplit > 1 && c->xcd_map) ? cdiv(bps * d.nsplit, 8) : 0;
@@ -318,6 +332,18 @@ static int launch_stream(vbmf_ctx* c, int pass, int ctrl_mode = 0, bool epi = fa
             } else {
                 using Cfg = StreamCfg<2>;
                 hipLaunchKernelGGL((stream_gemm_kernel<MODEc, 2, Cfg::NXWc, Cfg::DYc, Cfg::DFc, Cfg::Rc, 0, 1>), dim3(grid), dim3(256), lds,
+                                   c->stream, Y, F, out, XG, d.KS, d.steps_per_split, d.nsplit, ld, c->ints + I_STOP, ca, xper, ea);
+            }
+        });
+    } else if (c->narrow) {
+        DISPATCH_MODE(c->mode, {
+            if (c->NH == 1) {
+                using Cfg = NarrowCfg<1>;
+                hipLaunchKernelGGL((stream_gemm_kernel<MODEc, 1, Cfg::NXWc, Cfg::DYc, Cfg::DFc, Cfg::Rc>), dim3(grid), dim3(256), lds,
+                                   c->stream, Y, F, out, XG, d.KS, d.steps_per_split, d.nsplit, ld, c->ints + I_STOP, ca, xper, ea);
+            } else {
+                using Cfg = NarrowCfg<2>;
+                hipLaunchKernelGGL((stream_gemm_kernel<MODEc, 2, Cfg::NXWc, Cfg::DYc, Cfg::DFc, Cfg::Rc>), dim3(grid), dim3(256), lds,
                                    c->stream, Y, F, out, XG, d.KS, d.steps_per_split, d.nsplit, ld, c->ints + I_STOP, ca, xper, ea);
             }
         });
@@ -670,7 +696,7 @@ static int fold_Q_slabs(vbmf_ctx* c) {
 static int do_update_B(vbmf_ctx* c) {
     TRY(ensure_gram_A(c));
     // un-split pass at H <= 64: B, its tiles and the Gram partials come out of the pass's register epilogue
-    const bool epi = fused_gram(c) && c->d2.nsplit == 1 && (c->d2.XT / nxw_of(c->NH) + 3) / 4 <= c->gslab_cap;
+    const bool epi = fused_gram(c) && !c->narrow && c->d2.nsplit == 1 && (c->d2.XT / nxw_of(c->NH) + 3) / 4 <= c->gslab_cap;
     if (epi) {
         int nslab = 0;
         if (fused_ctrl(c)) {
@@ -860,8 +886,16 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
     c->kstep = kstep_of(c->mode);
     c->npart = npart_of(c->mode);
     const double ybytes = c->mode == MODE_F32 ? 4.0 : 2.0;
-    plan_pass(c->d1, M, L, c->kstep, c->NH, c->Hp, ybytes, c->o.pass1_splits);
-    plan_pass(c->d2, L, M, c->kstep, c->NH, c->Hp, ybytes, 0);
+    {   // narrow geometry when a pass of the wide one would have at most two column groups (VBMF_NARROW=0|1 forces it off|on).
+        // Measured (scripts/narrow_ab.sh): 10k x 1k, H = 32: 9 795 -> 11 724 sweeps/s; row shards of 100k x 10k (20+ column
+        // groups): no gain at 12.5k rows, 12 % slower at 25k and 50k rows -- hence the rule on the group count, not on bytes.
+        const char* ev = getenv("VBMF_NARROW");
+        const int wq = nxw_of(c->NH) * 4 * 32;                      // columns per workgroup of the wide geometry
+        const int64_t groups = std::min(cdiv(M, wq), cdiv(L, wq));
+        c->narrow = c->NH <= 2 && (ev ? atoi(ev) != 0 : groups <= 2);
+    }
+    plan_pass(c->d1, M, L, c->kstep, c->NH, c->Hp, ybytes, c->o.pass1_splits, c->narrow);
+    plan_pass(c->d2, L, M, c->kstep, c->NH, c->Hp, ybytes, 0, c->narrow);
     c->Mp = (int64_t)c->d1.XT * 32;
     c->Lp = (int64_t)c->d2.XT * 32;
     // the post kernel writes operand tiles for every 32-row tile of the factor: the consumer's KS must cover them
@@ -1536,7 +1570,7 @@ int vbmf_pass_bytes(vbmf_ctx* c, int pass, double* bytes) {
     else {
         // with the register epilogue (un-split pass, H <= 64) the launch writes B and re-reads B_old instead of writing
         // the product: SURVEY 8d's "B written and B_old re-read in pass 2"
-        const bool epi = c->NH <= 2 && c->d2.nsplit == 1 && (c->d2.XT / nxw_of(c->NH) + 3) / 4 <= c->gslab_cap;
+        const bool epi = c->NH <= 2 && !c->narrow && c->d2.nsplit == 1 && (c->d2.XT / nxw_of(c->NH) + 3) / 4 <= c->gslab_cap;
         *bytes = LM * ybytes + (double)c->M * c->H * 4.0 + (double)c->L * c->H * 4.0 * (epi ? 2.0 : 1.0);
     }
     return VBMF_OK;
