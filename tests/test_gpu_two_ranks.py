@@ -102,7 +102,7 @@ def test_three_ranks_one_gpu_host_transport(pkg, tmp_path):
     _check(pkg, 3, "host", tmp_path)
 
 
-@pytest.mark.parametrize("case", ["h128", "h200"])
+@pytest.mark.parametrize("case", ["h128", "h200", "straddle"])
 def test_two_ranks_large_rank_paths(pkg, tmp_path, case):
     _check(pkg, 2, "host", tmp_path, case)
 

@@ -26,11 +26,13 @@ def problem(L, M, H, seed):
 # 8-GPU BASELINE configuration (16 accumulator tiles per wave, un-fused post/Gram), "h200" the H > 128 control path.
 # "sparse" / "hetero": the ARD-sparse variant (homoscedastic / one noise precision per row) row-sharded.
 # "trial": the three-group variant with its hyper-prior fits (replicated M x H work: no further collective).
+# "straddle": the two shards (2049 / 2048 rows) sit on either side of the narrow-geometry threshold of the H <= 32 kernel;
+# the ranks must still agree on the padded width of the all-reduced Y'B partial (the decision uses the nominal shard size).
 CASES = {"h12": (1531, 700, 12), "h128": (1203, 520, 128), "h200": (901, 420, 200), "sparse": (1101, 480, 6),
-         "hetero": (1101, 480, 6), "trial": (1101, 480, 6)}
+         "hetero": (1101, 480, 6), "trial": (1101, 480, 6), "straddle": (4097, 2100, 12)}
 TRIAL_H0, TRIAL_M0 = 4, 190
 EPS, SEED = 0.0, 4242
-NITERS = {"h12": 12, "h128": 5, "h200": 5, "sparse": 8, "hetero": 8, "trial": 8}
+NITERS = {"h12": 12, "h128": 5, "h200": 5, "sparse": 8, "hetero": 8, "trial": 8, "straddle": 4}
 HYPER = dict(alpha0=1e-10, beta0=1e-10, gamma0=1e-10, delta0=1e-10, eta0=1e-10, zeta0=1e-10)
 
 

@@ -891,7 +891,10 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
         // groups): no gain at 12.5k rows, 12 % slower at 25k and 50k rows -- hence the rule on the group count, not on bytes.
         const char* ev = getenv("VBMF_NARROW");
         const int wq = nxw_of(c->NH) * 4 * 32;                      // columns per workgroup of the wide geometry
-        const int64_t groups = std::min(cdiv(M, wq), cdiv(L, wq));
+        // Every rank of a row-sharded job must take the SAME decision (the padded width of the all-reduced Y'B partial
+        // depends on it), so the row count that enters is the nominal shard size, not this rank's.
+        const int64_t Lnom = cdiv(c->Lg, c->o.nranks);
+        const int64_t groups = std::min(cdiv(M, wq), cdiv(Lnom, wq));
         c->narrow = c->NH <= 2 && (ev ? atoi(ev) != 0 : groups <= 2);
     }
     plan_pass(c->d1, M, L, c->kstep, c->NH, c->Hp, ybytes, c->o.pass1_splits, c->narrow);
