@@ -17,6 +17,10 @@ Prints ONE JSON line on rank 0.  `roofline` is for the streaming-contraction ker
 sweep are launches of it): algorithmic bytes per launch / average launch duration, measured with HIP
 events recorded on the library's own stream during the timed region.  `cpu_baseline` times the fp64
 oracle in the reference's operation order (OpenBLAS, all host cores) on a bounded row-sample.
+`control_chain_us`: last durations of the parts of the fp64 H x H control chain that rides in the pass launches
+(ctrl_end, SigmaA, lambda_max + loop test, SigmaB), stamped on the device.  `--shard-of N` runs rank 0's share of an N-rank
+job on one GPU; `--config cfg2|cfg4|cfg5` the other BASELINE shapes; `--full-cov` (with --config cfg5 --H <= 64) the
+per-column full-covariance branch of the sparse model.
 """
 import argparse
 import json
