@@ -66,16 +66,23 @@ def parse():
     ap.add_argument("--shard-of", type=int, default=0,
                     help="developer aid on ONE GPU: run rank 0's share of an N-rank strong-scaling job (L/N rows, "
                          "L_global = L, 1-rank communicator => the collective code path); an upper bound for N GPUs")
-    ap.add_argument("--cpu-rows", type=int, default=25000, help="row sample of the CPU baseline")
-    ap.add_argument("--cpu-sweeps", type=int, default=3)
+    ap.add_argument("--cpu-rows", type=int, default=0,
+                    help="rows of the CPU baseline (0 = all L rows: the faithful sweep holds an M x M product that does not "
+                         "scale with L, so a row sample cannot be extrapolated linearly)")
+    ap.add_argument("--cpu-sweeps", type=int, default=2)
+    ap.add_argument("--settle-seconds", type=float, default=0.3,
+                    help="untimed sweeps run for this long BEFORE the W warm-up sweeps, so that the device's clocks have ramped "
+                         "up from idle when the timed region starts (reported as clock_settle in the JSON line)")
     return ap.parse_args()
 
 
 def cpu_baseline(ctx, L, M, H, rows, sweeps, seed):
     """fp64 oracle, reference operation order ("faithful": three GEMM passes over Y, the Y.^2 and 2Y'
-    temporaries and the M x M product of updateSigma2!), on the first `rows` rows of the SAME matrix."""
+    temporaries and the M x M product of updateSigma2!, src/vbmf.jl:95-157), on the SAME matrix the GPU holds
+    (read back from the device).  All L rows by default: 2*M^2*H of the faithful sweep's flops (the M x M product,
+    src/vbmf.jl:154) do not scale with L, so timing a row sample and extrapolating linearly over-charges the CPU."""
     from oracle import vbmf_oracle as O          # checker/baseline only -- never on the product path
-    rows = int(min(rows, ctx.L))
+    rows = int(ctx.L if rows <= 0 else min(rows, ctx.L))
     Y = np.ascontiguousarray(ctx.get_Y(0, rows))
     rng = np.random.default_rng(seed)
     out = {}
@@ -93,13 +100,17 @@ def cpu_baseline(ctx, L, M, H, rows, sweeps, seed):
         threads = max([d.get("num_threads", 1) for d in threadpool_info()] or [os.cpu_count()])
     except Exception:
         threads = os.cpu_count()
+    full = rows == L
     scale = rows / float(L)
     return {
         "value": scale / out["faithful"], "unit": "sweeps/s", "cores": int(threads), "kind": "port",
-        "sample": f"first {rows} of {L} rows x {M} cols, H={H}, fp64 NumPy/OpenBLAS oracle in the reference's "
-                  f"operation order, median of {sweeps} sweeps = {out['faithful']:.3f} s, extrapolated linearly in L",
+        "sample": (f"all {L} rows x {M} cols" if full else f"first {rows} of {L} rows x {M} cols (extrapolated linearly in L: "
+                   "over-charges the L-independent M x M product)") +
+                  f", H={H}, fp64 NumPy/OpenBLAS oracle in the reference's operation order (src/vbmf.jl:95-157: three passes "
+                  f"over Y, Y.^2, 2Y', the M x M product), median of {sweeps} sweeps after one warm-up = {out['faithful']:.3f} s per sweep",
         "fused_value": scale / out["fused"],
         "sample_seconds_per_sweep": out["faithful"],
+        "rows": rows,
     }
 
 
@@ -178,6 +189,14 @@ def main():
         torch.cuda.synchronize()
         ctx.sync()
 
+    # clock settle: the device idles while the host prepares the initial state; untimed sweeps until it has been busy for
+    # --settle-seconds, then the W warm-up sweeps, then EXACTLY K timed sweeps
+    settle_sweeps = 0
+    if a.settle_seconds > 0:
+        ts = time.perf_counter()
+        while time.perf_counter() - ts < a.settle_seconds:
+            run(16)
+            settle_sweeps += 16
     if a.warmup > 0:
         run(a.warmup)
     ctx.profile_enable(max(1, a.event_stride))
@@ -205,15 +224,18 @@ def main():
     achieved = avg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     # HBM traffic per launch from PMC counters is collected in separate rocprofv3 passes
     # (scripts/pmc_traffic.sh); report the committed measurement when it is for exactly this workload
-    traffic = None
+    traffic, traffic_source = None, None
     try:
         import glob
-        pm = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_stream_kernel_cfg3.json")))[-1]))
+        pmf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_stream_kernel_cfg3.json")))[-1]
+        pm = json.load(open(pmf))
         k = pm["config"]
         if (k["L"], k["M"], k["H"], k["y_dtype"], k["n_gpus"]) == (L, M, H, ydt, world) and a.factor in ("auto", "bf16x2"):
             traffic = pm["traffic_bytes_per_launch"]
+            traffic_source = (f"profiles/{os.path.basename(pmf)} -- separate rocprofv3 --pmc passes of this workload "
+                              "(scripts/pmc_traffic.sh), NOT measured in this run")
     except Exception:
-        traffic = None
+        traffic, traffic_source = None, None
     # the other roof: MFMA work of one launch = 2*L*M*Hp flops per factor part (hi + lo in the bf16x2 mode); the pass
     # is priced against whichever roof it sits closer to (H <= 64: HBM; H >= 128 with hi+lo parts: MFMA)
     fop = "f32" if ydt == "f32" else ("bf16" if a.factor == "bf16" else "bf16x2")
@@ -240,7 +262,10 @@ def main():
                    "accumulate": "fp32", "hxh_algebra": "fp64", "row_shards": world},
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+            # whole sweep against the same roof: algorithmic bytes of both passes / wall time of a sweep (everything between
+            # the passes included: slab sum, post kernels, reductions, launch gaps)
+            "sweep_frac": (bytes1 + bytes2) / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS,
             "kernel": "stream_gemm_kernel (pass 1: Y'B; pass 2: Y*A, at H <= 64 with the B update + Gram partials as its "
                       "register epilogue; this rank's shard)",
             "bytes_per_launch": avg_bytes, "avg_launch_ms": avg_ms, "launches_timed": n,
@@ -251,6 +276,7 @@ def main():
                       "GBps": bytes2 / max(prof["pass2_ms"] / max(prof["pass2_n"], 1), 1e-9) / 1e6},
         },
         "final": {"sigma2": s["sigma2"], "d": d},
+        "clock_settle": {"seconds": a.settle_seconds, "untimed_sweeps": settle_sweeps},
         "control_chain_us": chain,
     }
     out["roofline"]["other_roof"] = {"bound": "mfma", "achieved": mfma_achieved, "peak": mfma_peak, "unit": "TFLOP/s",

@@ -36,7 +36,10 @@ typedef enum {
     VBMF_ERR_HIP = -3,         /* a HIP runtime call failed */
     VBMF_ERR_NUMERIC = -4,     /* non-positive pivot / non-finite value in the H x H algebra */
     VBMF_ERR_COMM = -5,        /* RCCL failure */
-    VBMF_ERR_UNSUPPORTED = -6
+    VBMF_ERR_UNSUPPORTED = -6,
+    VBMF_ERR_SYNC = -7         /* an in-launch hand-off gave up: the Y*A pass's register epilogue waited for the SigmaB
+                                  table longer than its bounded spin allows (the control workgroup of the same launch
+                                  did not run beside it); the state of that sweep is not valid */
 } vbmf_status;
 
 /* storage of Y on the device / arithmetic of the two streaming contractions */
@@ -138,8 +141,8 @@ int vbmf_elbo(vbmf_ctx* ctx, double* elbo);
  * Shapes: ATVecHat, diagSigmaATVec, CA, beta: M*H; BHat: L x H column-major; SigmaB: H x H; CB, delta: H.
  * sigmaHat is the noise PRECISION with Gamma posterior (eta, zeta) (src/vbmf_sparse.jl:35-39,321).
  * Derived constants (src/vbmf_sparse.jl:131,137,143): alpha = alpha0 + 1/2, gamma = gamma0 + L/2,
- * eta = eta0 + L*M/2 (L = L_global).  The full-covariance branch (dense MH x MH) and diag_var=true are
- * out of scope. */
+ * eta = eta0 + L*M/2 (L = L_global).  diag_var=true: VBMF_VARIANT_*_DIAGVAR + vbmf_sparse_set_noise_rows below;
+ * full_cov=true: vbmf_sparse_set_full_cov below (per-column H x H blocks; the dense MH x MH fields are never formed). */
 typedef struct { double alpha0, beta0, gamma0, delta0, eta0, zeta0; } vbmf_sparse_hyper;
 
 #define VBMF_SSTEP_A 1      /* updateA! diagonal branch  src/vbmf_sparse.jl:204-247 */
@@ -172,6 +175,13 @@ int vbmf_sparse_run(vbmf_ctx* ctx, int64_t niter, double eps, int est_cb, int64_
 /* lowerBound (src/vbmf_sparse.jl:435-471), verbatim quirks QS4; H(B) as L*logdet(SigmaB), clamped like
  * normalEntropy's det (src/util.jl:118-122) when clamp != 0 */
 int vbmf_sparse_lower_bound(vbmf_ctx* ctx, int clamp, double* lb);
+/* lowerBoundTrimmed (src/vbmf_sparse.jl:478-489; dual src/vbmf_dual.jl:606-617; trial src/vbmf_trial.jl:687-698; called by
+ * examples/mil_util.jl:505): the bound with the entries of vec(A') whose |ATVecHat| <= trim removed from ATVecHat, beta, CA,
+ * diagSigmaATVec and MH -- a mask in front of the M*H-long sums (AHat itself, and with it Y*AHat and AHat'AHat, stays
+ * whole, as in the reference, which trims the vec fields only; the grouped models' per-group fields beta0/beta1/CA0/...
+ * are not trimmed there either, so for them only MH, the CA-weighted second moment and H(vec(A')) change).
+ * The comparison runs on the device's fp32 copy of ATVecHat. */
+int vbmf_sparse_lower_bound_trimmed(vbmf_ctx* ctx, int clamp, double trim, double* lb);
 /* full_cov = true of updateA! (src/vbmf_sparse.jl:178-202; dual :218-243; trial :252-277).  The reference's dense MH x MH
  * invSigmaATVec = sigmaHat*kron(I_M, B'B + L*SigmaB) + diag(CA) is block diagonal, so the device inverts the M H x H blocks
  * (one workgroup per column of Y) and never forms it: diagSigmaATVec = the blocks' diagonals, SigmaA = their sum (a full
@@ -260,12 +270,16 @@ int vbmf_device_sync(vbmf_ctx* ctx);
 #define VBMF_PEEK_FB 5     /* BHat MFMA operand tiles */
 #define VBMF_PEEK_Y1 6     /* Y tiled for pass 1 */
 #define VBMF_PEEK_Y2 7     /* Y tiled for pass 2 */
-#define VBMF_PEEK_DIMS 8   /* int32 x 16: Hp, NH, mode, XT1, KS1, nsplit1, sps1, XT2, KS2, nsplit2, sps2, kstep, npart */
+#define VBMF_PEEK_DIMS 8   /* int32 x 16: Hp, NH, mode, XT1, KS1, nsplit1, sps1, XT2, KS2, nsplit2, sps2, kstep, npart, narrow */
 #define VBMF_PEEK_CHAIN 9  /* uint64 x 4 (8 words): last durations of the in-launch control chain's parts in 10 ns ticks:
                               ctrl_end, SigmaA, lambda_max(dB'dB) + loop test, SigmaB */
 int vbmf_debug_peek(vbmf_ctx* ctx, int what, uint32_t* out, int64_t nwords, int64_t word_offset);
 /* tuning hook: average milliseconds of `iters` back-to-back launches of streaming pass p (1|2) alone */
 int vbmf_debug_time_pass(vbmf_ctx* ctx, int pass, int iters, double* ms);
+/* test hooks for the in-launch hand-off of the Y*A pass's register epilogue (VBMF_ERR_SYNC path) */
+#define VBMF_DEBUG_EPI_SPIN_LIMIT 0   /* polls (~0.4 us each) the epilogue waits for the SigmaB table before giving up; default 2^22 */
+#define VBMF_DEBUG_EPI_EXPECT_SKEW 1  /* != 0: the epilogue waits for a sequence number nobody publishes (forces the timeout) */
+int vbmf_debug_set(vbmf_ctx* ctx, int what, int64_t value);
 
 #ifdef __cplusplus
 }

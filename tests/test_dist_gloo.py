@@ -1,5 +1,5 @@
 """world_size-2 CPU test (gloo) of the row-sharded sweep: the same two all-reduces the library issues
-over RCCL (M x H partial of Y'B; packed B Grams) reproduce the unsharded oracle, and the replicated
+over RCCL (M x H partial of Y'B; packed B Grams + the row-local part of tr(B'YA)) reproduce the unsharded oracle, and the replicated
 quantities stay bit-identical across ranks."""
 import os
 import socket
@@ -65,12 +65,12 @@ def _worker(rank, world, port, q):
             Qg = Yg @ A
             Bnew = (Qg @ SigmaB) / s2
             dB = Bg - Bnew
-            packed = allreduce(np.stack([Bnew.T @ Bnew, dB.T @ dB]))   # collective 2
-            GBold, GB, GD = GB, packed[0], packed[1]
+            # collective 2: ONE packed message [B'B | dB'dB | tr(B'YA) = sum (Y_g A) o B_g], as the library sends it
+            packed = allreduce(np.concatenate([(Bnew.T @ Bnew).ravel(), (dB.T @ dB).ravel(), [np.sum(Qg * Bnew)]]))
+            GBold, GB, GD, tr = GB, packed[:H * H].reshape(H, H), packed[H * H:2 * H * H].reshape(H, H), float(packed[-1])
             Bg = Bnew
             ca = np.diag(GA) / M + np.diag(SigmaA)
             cb = np.diag(GB) / L + np.diag(SigmaB)
-            tr = float(np.sum(KB * GB))                                # tr(Y'BA') = tr(KB B'B): B = Q inv(KB)
             s2 = (trYY - 2 * tr + np.sum((GA + M * SigmaA) * (GB + L * SigmaB))) / (L * M)
             ds.append(np.sqrt(np.linalg.eigvalsh(GD)[-1] / np.linalg.eigvalsh(GBold)[-1]))
         tro = []

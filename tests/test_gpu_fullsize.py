@@ -1,4 +1,5 @@
-"""Parity at BASELINE.json's FULL sizes: config 3 (100 000 x 10 000, H = 64, bf16 Y) and
+"""Parity at BASELINE.json's FULL sizes: config 3 (100 000 x 10 000, H = 64, bf16 Y), config 4
+(1M x 10k, H = 128: one rank's 125 000-row share against the oracle, the whole matrix through its properties) and
 config 5 (ARD-sparse, H = 256) against the fp64 oracle fed the matrix exactly as the device stores it
 (`vbmf_get_Y`), plus size-independent properties of the sweep.  The oracle needs the 8 GB fp64 Y on the host and
 ~0.3-1 TFLOP of fp64 BLAS per sweep, so the trajectories are short (3 resp. 2 sweeps).  Tolerances as in
@@ -119,3 +120,86 @@ def test_config5_full_size_sparse_two_sweeps(pkg):
     assert n == 2
     assert max(v for k, v in errs.items() if k not in ("sigmaHat", "d", "lowerBound")) < 1e-3, errs
     assert errs["sigmaHat"] < 4e-3 and errs["d"] < 2e-2 and errs["lowerBound"] < 1e-3, errs
+
+
+# ---- BASELINE config 4: 1M x 10k, H = 128, Y row-sharded over 8 GPUs ---------------------------------------------------------
+L4, M4, H4, SHARDS4 = 1000000, 10000, 128, 8
+
+
+def test_config4_rank_share_vs_oracle(pkg):
+    """One rank's share of config 4 at its REAL size: 125 000 x 10 000, H = 128, bf16 Y, the collective code path
+    (1-rank RCCL communicator: slab sum, out-of-place all-reduces of Y'B and of [B'B | dB'dB | tr(B'YA)]), two sweeps against
+    the fused fp64 oracle on the matrix exactly as the device stores it (10 GB on the host, ~0.6 TFLOP per sweep).
+    Tolerances: config 3's (bf16x2 path)."""
+    Ls, H = L4 // SHARDS4, H4
+    rng = np.random.default_rng(20170102)
+    A0, B0 = rng.standard_normal((M4, H)), rng.standard_normal((Ls, H))
+    z = np.zeros((H, H))
+    with pkg.capi.Context(Ls, M4, H, y_dtype=pkg.VBMF_Y_BF16, nranks=1, rank=0, L_global=Ls, row_offset=0) as c:
+        c.comm_init(pkg.capi.Context.unique_id())
+        c.set_Y_synthetic(20170101, H, 0.05)
+        c.set_state(A0, B0, z, z, 0.1 * np.ones(H), 0.1 * np.ones(H), 0.1)
+        it, d, tr = c.run(2, eps=0.0, est_covs=True, est_var=True, want_trace=True)
+        s = c.get_state()
+        trYY = c.trYY()
+        dims = c.dims()
+        Ys = c.get_Y()
+    assert it == 2 and dims["NH"] == 4
+    assert abs(float(np.vdot(Ys, Ys)) - trYY) <= 1e-12 * trYY
+    po = O.vbmf_parameters()
+    po.L, po.M, po.H = Ls, M4, H
+    po.AHat, po.BHat = A0.copy(), B0.copy()
+    po.SigmaA = np.zeros((H, H)); po.SigmaB = np.zeros((H, H))
+    po.CA = 0.1 * np.eye(H); po.CB = 0.1 * np.eye(H); po.invCA = 10 * np.eye(H); po.invCB = 10 * np.eye(H)
+    po.sigma2 = 0.1
+    otr = []
+    O.vbmf_(Ys, po, 2, eps=0.0, est_covs=True, est_var=True, fused=True, trace=otr)
+    del Ys
+    gc.collect()
+    errs = dict(A=relF(s["AHat"], po.AHat), B=relF(s["BHat"], po.BHat), SA=relF(s["SigmaA"], po.SigmaA),
+                SB=relF(s["SigmaB"], po.SigmaB), ca=relF(s["CA_diag"], np.diag(po.CA)),
+                cb=relF(s["CB_diag"], np.diag(po.CB)), s2=abs(s["sigma2"] - po.sigma2) / po.sigma2,
+                d=abs(d - otr[-1][0]) / otr[-1][0], elbo=abs(tr[-1, 2] - otr[-1][2]) / abs(otr[-1][2]))
+    report(f"cfg4 RANK SHARE {Ls}x{M4} H={H} bf16x2 (1 of {SHARDS4} shards of 1M x 10k, collective path), 2 sweeps: "
+           + " ".join(f"{k}={v:.2e}" for k, v in errs.items()) + f"  [plan: pass1 nsplit {dims['nsplit1']}, pass2 nsplit {dims['nsplit2']}]")
+    assert max(errs[k] for k in ("A", "B", "SA", "SB", "ca", "cb")) < 4e-4, errs
+    assert errs["s2"] < 4e-3 and errs["d"] < 5e-3 and errs["elbo"] < 1e-4, errs
+
+
+def test_config4_whole_matrix_properties(pkg):
+    """The whole 1M x 10k matrix of config 4 on ONE GPU (two tiled bf16 copies, 40 GB), H = 128: no host copy of it can
+    exist (80 GB fp64), so the checks are the size-independent properties used at config 3 -- bit-determinism, ascent of
+    the bound with frozen hyper-parameters, ||Y||^2 -- plus the generator's independence of the sharding at this scale:
+    a 4096-row window of the 1M-row matrix equals, bit for bit, the same window generated as its own shard."""
+    H = H4
+    rng = np.random.default_rng(20170102)
+    A0 = rng.standard_normal((M4, H))
+    B0 = rng.standard_normal((L4, H))
+    z = np.zeros((H, H))
+    ones = 0.1 * np.ones(H)
+    win0, wn = 531072, 4096
+    with pkg.capi.Context(L4, M4, H, y_dtype=pkg.VBMF_Y_BF16) as c:
+        c.set_Y_synthetic(20170101, H, 0.05)
+        trYY = c.trYY()
+        window = c.get_Y(win0, wn)
+        c.set_state(A0, B0, z, z, ones, ones, 0.1)
+        it, d, tr = c.run(2, eps=0.0, est_covs=True, est_var=True, want_trace=True)
+        s = c.get_state(want_B=False)
+        c.set_state(A0, B0, z, z, ones, ones, 0.1)
+        it2, d2, tr2 = c.run(2, eps=0.0, est_covs=True, est_var=True, want_trace=True)
+        s2 = c.get_state(want_B=False)
+        assert it == it2 == 2 and d2 == d and np.array_equal(tr2[:, :3], tr[:, :3])
+        assert np.array_equal(s2["AHat"], s["AHat"]) and np.array_equal(s2["SigmaB"], s["SigmaB"]) and s2["sigma2"] == s["sigma2"]
+        c.set_state(A0, B0, z, z, ones, ones, 0.1)
+        it3, d3, tr3 = c.run(4, eps=0.0, est_covs=False, est_var=False, want_trace=True)
+        e = tr3[:, 2]
+    report(f"cfg4 WHOLE MATRIX {L4}x{M4} H={H}: trYY/(LM) = {trYY / (L4 * M4):.6f}; sigma2 after 2 sweeps {s['sigma2']:.6e}; "
+           "frozen-hyperparameter ELBO trace " + " ".join(f"{v:.6e}" for v in e))
+    assert it3 == 4 and np.all(np.isfinite(e)) and np.all(np.diff(e) >= -1e-5 * np.abs(e[:-1])), e
+    # toy_matrix entries are N(0,1) (one latent column per matrix column) + N(0, 0.05^2): second moment 1.0025 (1e10 samples)
+    assert abs(trYY / (L4 * M4) - 1.0025) < 2e-3, trYY / (L4 * M4)
+    assert np.isfinite(s["sigma2"]) and s["sigma2"] > 0
+    with pkg.capi.Context(wn, M4, H, y_dtype=pkg.VBMF_Y_BF16, nranks=1, rank=0, L_global=wn, row_offset=win0) as c:
+        c.set_Y_synthetic(20170101, H, 0.05)
+        shard = c.get_Y()
+    assert np.array_equal(shard, window)

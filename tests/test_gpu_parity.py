@@ -117,7 +117,10 @@ def test_run_three_sweeps(pkg, mode, L, M, H):
     pg = to_pkg_params(pkg, po)
     pkg.vbmf_(Ys, pg, 3, eps=0.0, est_covs=True, est_var=True)
     _, n, d = O.vbmf_(Ys, po, 3, eps=0.0, est_covs=True, est_var=True)
-    tol3 = {k: 6 * v for k, v in tol.items()}
+    # three sweeps accumulate the per-update error of the factors and covariances (measured worst case: BHat 8.2e-5 on the f32
+    # path at 1200 x 900, H = 128, against 5e-5 per update); sigma2 keeps its stated per-dtype tolerance UNMULTIPLIED: tr(Y'BA')
+    # is summed directly where BHat is produced (no Gram identity on a rounded BHat any more)
+    tol3 = {k: (v if k == "sigma2" else 2 * v) for k, v in tol.items()}
     if mode == "bf16":
         # single-bf16 factors: ~3 significant digits in A/B; the noise variance (a cancellation of
         # O(||Y||^2) terms) is only meaningful with the hi+lo operand -- checked loosely here
@@ -157,7 +160,10 @@ def test_run_trajectory_well_conditioned(pkg, mode, L, M, H):
     assert max(errs[k] for k in ("A", "B", "ca", "cb")) < 20 * tol["default"], errs
     # Sigma = sigma2*inv(.) inherits sigma2's cancellation error
     assert max(errs[k] for k in ("SA", "SB", "s2")) < 20 * tol["sigma2"], errs
-    assert np.allclose(tr[:, 0], otr[:, 0], rtol=5e-3 if mode == "f32" else 3e-2, atol=D_ATOL)
+    # bf16x2: BHat is stored as bf16 hi + lo, a grid of 2^-17 relative per entry, so near convergence d is the norm of a few
+    # one-step flips on that grid: 7.6e-6 / sqrt(L*H) per flipped entry (1e-6 .. 3e-6 on the 10 x 2 factor) where the
+    # oracle's d keeps falling -- the floor DESIGN.md section 2 states for `eps`
+    assert np.allclose(tr[:, 0], otr[:, 0], rtol=5e-3 if mode == "f32" else 3e-2, atol=D_ATOL if mode == "f32" else 1e-5)
     assert np.allclose(tr[:, 1], otr[:, 1], rtol=20 * tol["sigma2"])
     assert np.allclose(tr[:, 2], otr[:, 2], rtol=1e-3, atol=1.0)
 

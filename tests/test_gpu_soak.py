@@ -87,3 +87,36 @@ def test_numeric_error_leaves_the_handle_usable(pkg):
         c.set_state(rng.standard_normal((M, H)), rng.standard_normal((L, H)), z, z, 0.1 * np.ones(H), 0.1 * np.ones(H), 0.1)
         it, d, _ = c.run(3, eps=0.0, est_covs=True, est_var=True)
         assert it == 3 and np.isfinite(d) and np.all(np.isfinite(c.get_state()["BHat"]))
+
+
+def test_epilogue_handoff_timeout_is_reported(pkg):
+    """The Y*A pass's register epilogue waits (bounded) for the SigmaB table that control workgroup 0 of the SAME launch
+    releases.  Force the wait to fail (the epilogue is told to expect a sequence number nobody publishes, with a short spin
+    limit): the run must come back with VBMF_ERR_SYNC and its own message -- not hang, not be folded into the pivot error --
+    and the handle must run normally afterwards.  (In every other GPU test a run that returns OK has I_ERR == 0 on the
+    device: vbmf_run fails on any non-zero value.)"""
+    L, M, H = 70000, 1100, 48                                   # un-split Y*A pass at H <= 64: the register-epilogue path
+    rng = np.random.default_rng(5)
+    A0, B0 = rng.standard_normal((M, H)), rng.standard_normal((L, H))
+    z = np.zeros((H, H))
+    with pkg.capi.Context(L, M, H, y_dtype=pkg.VBMF_Y_BF16) as c:
+        dims = c.dims()
+        if dims["nsplit2"] != 1 or dims["NH"] > 2 or dims["narrow"]:
+            pytest.skip(f"planner did not choose the un-split pass here: {dims}")
+        c.set_Y_synthetic(11, H, 0.05)
+        c.set_state(A0, B0, z, z, 0.1 * np.ones(H), 0.1 * np.ones(H), 0.1)
+        it, d, _ = c.run(3, eps=0.0, est_covs=True, est_var=True)
+        ok = c.get_state()
+        assert it == 3 and np.isfinite(d)
+        c.debug_set(pkg.capi.DEBUG_EPI_SPIN_LIMIT, 2000)        # ~1 ms
+        c.debug_set(pkg.capi.DEBUG_EPI_EXPECT_SKEW, 1)
+        c.set_state(A0, B0, z, z, 0.1 * np.ones(H), 0.1 * np.ones(H), 0.1)
+        with pytest.raises(pkg.VbmfError) as ei:
+            c.run(3, eps=0.0, est_covs=True, est_var=True)
+        assert ei.value.code == pkg.capi.VBMF_ERR_SYNC and "hand-off" in str(ei.value), ei.value
+        c.debug_set(pkg.capi.DEBUG_EPI_EXPECT_SKEW, 0)
+        c.debug_set(pkg.capi.DEBUG_EPI_SPIN_LIMIT, 1 << 22)
+        c.set_state(A0, B0, z, z, 0.1 * np.ones(H), 0.1 * np.ones(H), 0.1)
+        it, d2, _ = c.run(3, eps=0.0, est_covs=True, est_var=True)
+        again = c.get_state()
+        assert it == 3 and d2 == d and np.array_equal(again["BHat"], ok["BHat"])

@@ -31,7 +31,10 @@ SYMBOLS = [
     "vbmf_preprocess_close", "vbmf_dual_set_priors", "vbmf_dual_get_priors", "vbmf_dual_run",
     "vbmf_trial_set_priors", "vbmf_trial_get_priors", "vbmf_trial_run",
     "vbmf_sparse_set_full_cov", "vbmf_sparse_set_SigmaA", "vbmf_sparse_get_SigmaA",
+    "vbmf_sparse_lower_bound_trimmed", "vbmf_debug_set",
 ]
+VBMF_OK, VBMF_ERR_INVALID, VBMF_ERR_NO_DEVICE, VBMF_ERR_HIP, VBMF_ERR_NUMERIC, VBMF_ERR_COMM, VBMF_ERR_UNSUPPORTED, VBMF_ERR_SYNC = 0, -1, -2, -3, -4, -5, -6, -7
+DEBUG_EPI_SPIN_LIMIT, DEBUG_EPI_EXPECT_SKEW = 0, 1
 SSTEP_A, SSTEP_B, SSTEP_CA, SSTEP_CB, SSTEP_SIGMA, SSTEP_PRIORS = 1, 2, 4, 8, 16, 32
 PEEK_P, PEEK_Q, PEEK_A32, PEEK_B32, PEEK_FA, PEEK_FB, PEEK_Y1, PEEK_Y2, PEEK_DIMS, PEEK_CHAIN = range(10)
 
@@ -115,6 +118,8 @@ def lib():
     L.vbmf_sparse_step.argtypes = [vp, i32]
     L.vbmf_sparse_run.argtypes = [vp, i64, C.c_double, i32, C.POINTER(i64), dp, dp]
     L.vbmf_sparse_lower_bound.argtypes = [vp, i32, dp]
+    L.vbmf_sparse_lower_bound_trimmed.argtypes = [vp, i32, C.c_double, dp]
+    L.vbmf_debug_set.argtypes = [vp, i32, i64]
     L.vbmf_sparse_set_full_cov.argtypes = [vp, i32]
     L.vbmf_sparse_set_SigmaA.argtypes = [vp, dp]
     L.vbmf_sparse_get_SigmaA.argtypes = [vp, dp]
@@ -363,6 +368,11 @@ class Context:
         self._chk(self._lib.vbmf_sparse_lower_bound(self._h, int(clamp), C.byref(v)))
         return v.value
 
+    def sparse_lower_bound_trimmed(self, trim=1e-1, clamp=True):
+        v = C.c_double()
+        self._chk(self._lib.vbmf_sparse_lower_bound_trimmed(self._h, int(clamp), float(trim), C.byref(v)))
+        return v.value
+
     # ---- two-group ARD variant (variant=VBMF_VARIANT_DUAL_DIAG) ----
     def dual_set_priors(self, H0, alpha00, beta00, alpha01, beta01, alpha0=None, alpha1=None):
         alpha0 = alpha00 + 0.5 if alpha0 is None else alpha0
@@ -451,7 +461,7 @@ class Context:
 
     def dims(self):
         v = self.peek(PEEK_DIMS, 16, dtype=np.int32)
-        keys = ["Hp", "NH", "mode", "XT1", "KS1", "nsplit1", "sps1", "XT2", "KS2", "nsplit2", "sps2", "kstep", "npart"]
+        keys = ["Hp", "NH", "mode", "XT1", "KS1", "nsplit1", "sps1", "XT2", "KS2", "nsplit2", "sps2", "kstep", "npart", "narrow"]
         return dict(zip(keys, (int(x) for x in v)))
 
     def time_pass(self, p, iters=10):
@@ -461,3 +471,6 @@ class Context:
 
     def sync(self):
         self._chk(self._lib.vbmf_device_sync(self._h))
+
+    def debug_set(self, what, value):
+        self._chk(self._lib.vbmf_debug_set(self._h, int(what), int(value)))

@@ -22,15 +22,18 @@ struct StateLayout {
     __host__ __device__ long long GA() const { return 0; }
     __host__ __device__ long long GB() const { return n2(); }
     __host__ __device__ long long GD() const { return 2 * n2(); }     // must follow GB (one all-reduce)
-    __host__ __device__ long long SA() const { return 3 * n2(); }
-    __host__ __device__ long long SB() const { return 4 * n2(); }
-    __host__ __device__ long long KB() const { return 5 * n2(); }     // matrix inverted for SigmaB
-    __host__ __device__ long long W0() const { return 6 * n2(); }     // scratch (H > 128)
-    __host__ __device__ long long W1() const { return 7 * n2(); }
-    __host__ __device__ long long W2() const { return 8 * n2(); }
-    __host__ __device__ long long ca() const { return 9 * n2(); }
-    __host__ __device__ long long cb() const { return 9 * n2() + Hp; }
-    __host__ __device__ long long scal() const { return 9 * n2() + 2 * Hp; }
+    // GX: 8 doubles right behind GD, so that [GB | GD | GX] is ONE contiguous all-reduce target; GX[0] = tr(B'YA) = the
+    // direct sum  sum_{l,h} (Y A)[l,h] * BHat[l,h]  over this rank's rows, formed where BHat is produced
+    __host__ __device__ long long GX() const { return 3 * n2(); }
+    __host__ __device__ long long SA() const { return 3 * n2() + 8; }
+    __host__ __device__ long long SB() const { return 4 * n2() + 8; }
+    __host__ __device__ long long KB() const { return 5 * n2() + 8; }     // matrix inverted for SigmaB
+    __host__ __device__ long long W0() const { return 6 * n2() + 8; }     // scratch (H > 128)
+    __host__ __device__ long long W1() const { return 7 * n2() + 8; }
+    __host__ __device__ long long W2() const { return 8 * n2() + 8; }
+    __host__ __device__ long long ca() const { return 9 * n2() + 8; }
+    __host__ __device__ long long cb() const { return 9 * n2() + 8 + Hp; }
+    __host__ __device__ long long scal() const { return 9 * n2() + 8 + 2 * Hp; }
     __host__ __device__ long long total() const { return scal() + 32; }
 };
 enum : int { S_SIGMA2 = 0, S_TRYY, S_LOGDET_SA, S_LOGDET_SB, S_LAMB_PREV, S_LAMB_NEW, S_LAMD, S_D, S_ELBO,
@@ -373,7 +376,6 @@ __device__ __forceinline__ void ctrl_cov_dev(double* __restrict__ st, StateLayou
             if (i < H && j < H) {
                 v = G[(long long)i * Hp + j] + N * Sother[(long long)i * Hp + j];
                 if (i == j) v += sigma2 / cdiag[i];
-                if (which == 1) st[lay.KB() + (long long)i * Hp + j] = v;
             }
             Kg[t] = v;
         }
@@ -397,7 +399,6 @@ __device__ __forceinline__ void ctrl_cov_dev(double* __restrict__ st, StateLayou
                 if (i < H && j < H) {
                     v = G[(long long)i * Hp + j] + N * Sother[(long long)i * Hp + j];
                     if (i == j) v += sigma2 / cdiag[i];
-                    if (which == 1) st[lay.KB() + (long long)i * Hp + j] = v;
                 }
                 w[a][b] = v;
             }
@@ -642,7 +643,8 @@ __global__ __launch_bounds__(1024) void eig_power_kernel(double* __restrict__ st
 }
 
 // flags: bit0 est_covs->CA, bit1 est_covs->CB, bit2 est_var, bit3 compute d + loop bookkeeping,
-//        bit4 tr(Y'BA') from the Gram identity tr(KB o GB) (else from scal[S_TRDOT]),
+//        bit4 (unused; tr(Y'BA') is always the direct sum st[GX] = sum (Y A) o BHat left by the kernel that produced BHat,
+//             or by prepare_trYBA -- the Gram identity tr(KB o GB) it replaces is exact only for an un-rounded BHat),
 //        bit5 S_LAMB_PREV already holds lambda_max of the old B'B (no rotation from S_LAMB_NEW)
 //        bit6 split schedule (ctrl_chain): the d / loop part (bit3) is done by ctrl_loop_dev in another workgroup;
 //             this call only files sigma2 / ELBO / residual in trace row it_row
@@ -660,45 +662,43 @@ __device__ __forceinline__ void ctrl_end_dev(double* __restrict__ st, StateLayou
     const double* GB = st + lay.GB();
     const double* SA = st + lay.SA();
     const double* SB = st + lay.SB();
-    const double* KB = st + lay.KB();
     double* ca = st + lay.ca();
     double* cb = st + lay.cb();
     double* scal = st + lay.scal();
     const int stopped = load_stop(ints);
     const int hme = threadIdx.x;                                 // H <= 256 <= blockDim.x: one diagonal entry per thread
     const double scv = hme < 32 ? scal[hme] : 0.0;
+    const double trdot = st[lay.GX()];                           // tr(Y'BA') = sum (Y A) o BHat, summed where BHat was produced
     double ca_h = hme < H ? ca[hme] : 1.0, cb_h = hme < H ? cb[hme] : 1.0;
 
-    // tr(Y'BA') and tr((A'A + M SigmaA)(B'B + L SigmaB)); 8 elements per thread and round, all loads before the first use
-    double t1 = 0.0, t2 = 0.0;
+    // tr((A'A + M SigmaA)(B'B + L SigmaB)); 8 elements per thread and round, all loads before the first use
+    double t2 = 0.0;
     {
         constexpr int U = 8;
         const int sh = 31 - __clz(Hp), total = Hp * Hp;          // Hp is a power of two
         for (int e0 = threadIdx.x; e0 < total; e0 += U * blockDim.x) {
-            double kb[U], gb[U], ga[U], sa[U], sb[U];
+            double gb[U], ga[U], sa[U], sb[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int e = e0 + u * blockDim.x;
                 const bool ok = e < total && (e >> sh) < H && (e & (Hp - 1)) < H;
                 const int ee = ok ? e : 0;
-                kb[u] = KB[ee]; gb[u] = GB[ee]; ga[u] = GA[ee]; sa[u] = SA[ee]; sb[u] = SB[ee];
-                if (!ok) { kb[u] = 0.0; ga[u] = 0.0; sa[u] = 0.0; }
+                gb[u] = GB[ee]; ga[u] = GA[ee]; sa[u] = SA[ee]; sb[u] = SB[ee];
+                if (!ok) { ga[u] = 0.0; sa[u] = 0.0; }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int e = e0 + u * blockDim.x;
                 const int i = e >> sh, j = e & (Hp - 1);
                 if (e < total && i == j && i < H) { dg[0][i] = ga[u]; dg[1][i] = sa[u]; dg[2][i] = gb[u]; dg[3][i] = sb[u]; }
-                t1 += kb[u] * gb[u];
                 t2 += (ga[u] + M * sa[u]) * (gb[u] + Lg * sb[u]);
             }
         }
     }
     if (stopped) return;                                         // uniform
     if (hme < 32) sc_s[hme] = scv;
-    t1 = block_sum(t1, red);                                     // (its barriers publish sc_s and dg)
-    t2 = block_sum(t2, red);
-    const double trYBA = (flags & 16) ? t1 : sc_s[S_TRDOT];
+    t2 = block_sum(t2, red);                                     // (its barriers publish sc_s and dg)
+    const double trYBA = trdot;
     const double resid = sc_s[S_TRYY] - 2.0 * trYBA + t2;
     double e = 0.0;
     if (hme < H) {

@@ -67,6 +67,34 @@ __device__ __forceinline__ void write_factor_tiles(uint4* __restrict__ Ft, f32x1
     }
 }
 
+// ---- tr(B'YA) = sum_{l,h} (Y A)[l,h] * BHat[l,h], formed where BHat is produced (src/vbmf.jl:154: trace(2*Y'*BHat*AHat')) ----
+// One 32 x 32 block of it.  The product block is held "lane = row" (q[t] on lane (half, c) = Q[x0 + c][h0 + k(t, half)],
+// k = rho for fragment-major products, 2t + half for row-major ones) and the new factor block "lane = column"
+// (b[r] = B[x0 + rho(r, half)][h0 + c], AFTER write_factor_tiles made it the value the tiles encode), so B goes through a
+// 32 x 33 LDS tile of this wave (conflict-free both ways) and comes back transposed.  Returns this lane's partial sum.
+// (The Gram identity tr(KB * B'B) used before is exact only for an un-rounded B = Q * inv(KB): with B stored as bf16 hi + lo
+//  and Sigma/sigma2 as an fp32 table its error, amplified ~400x by sigma2's cancellation, reached 1.5e-3 at 1200 x 900, H = 128.)
+constexpr int TB_LD = 33;
+template <bool RHO>
+__device__ __forceinline__ float tile_dot_qb(const float (&q)[16], const f32x16& b, float* tb, int lane) {
+    const int c = lane & 31, half = lane >> 5;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tb[rho(r, half) * TB_LD + c] = b[r];
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // LDS operations of one wave execute in issue order
+    __builtin_amdgcn_wave_barrier();
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) s = fmaf(q[t], tb[c * TB_LD + (RHO ? rho(t, half) : 2 * t + half)], s);
+    return s;
+}
+// this wave's share of tr(B'YA): lanes folded in fixed order, one double per wave (summed later in fixed order too)
+__device__ __forceinline__ void store_wave_dot(double v, double* __restrict__ slot, int lane) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if (lane == 0) *slot = v;
+}
+
 // One wave per NXT consecutive 32-row tiles of the factor (NXT = 1 up to H = 64; from H = 128 on several tiles share
 // every fetch of the H x H table, which no longer fits a wave's registers: 16 accumulator tiles per wave).
 // In: [nslab][Hp][ldIn] fp32 (x fastest), S: [Hp][Hp] fp32 row-major, Fac: [XT*32][Hp] fp32 row-major.
@@ -77,13 +105,17 @@ __global__ __launch_bounds__(256) void post_kernel(const float* __restrict__ In,
                                                    long long slabStride, const float* __restrict__ S,
                                                    float* __restrict__ Fac, uint4* __restrict__ Ft,
                                                    const unsigned char* __restrict__ mask, int hmask_start, int XT,
-                                                   const int* __restrict__ stop) {
+                                                   const int* __restrict__ stop, double* __restrict__ trpart = nullptr) {
     constexpr int Hp = NH * 32;
     constexpr int NXT = PostCfg<NH>::NXT;
+    __shared__ float tbuf[4][32 * TB_LD];
     if (stop && *stop) return;
     const int lane = threadIdx.x & 63;
     const int xt0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * NXT;
-    if (xt0 >= XT) return;
+    if (xt0 >= XT) {
+        if (trpart && lane == 0) trpart[blockIdx.x * 4 + (threadIdx.x >> 6)] = 0.0;
+        return;
+    }
     const int c = lane & 31, half = lane >> 5;
 
     f32x16 acc[NXT][NH];
@@ -138,6 +170,28 @@ __global__ __launch_bounds__(256) void post_kernel(const float* __restrict__ In,
             for (int r = 0; r < 16; ++r) Fac[(x0 + rho(r, half)) * Hp + hcol] = acc[i][h][r];
         }
     }
+    if (trpart) {                                            // tr(B'YA): the product rows again (L2-hot), block by block
+        double tr = 0.0;
+        float* tb = tbuf[threadIdx.x >> 6];
+#pragma unroll
+        for (int i = 0; i < NXT; ++i) {
+            const int xt = xt0 + i;
+            if (xt >= XT) break;
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                float q[16];
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const float* ip = In + (long long)(h * 32 + 2 * t + half) * ldIn + (long long)xt * 32 + c;
+                    float v = 0.f;
+                    for (int sl = 0; sl < nslab; ++sl) v += ip[(long long)sl * slabStride];
+                    q[t] = v;
+                }
+                tr += (double)tile_dot_qb<false>(q, acc[i][h], tb, lane);
+            }
+        }
+        store_wave_dot(tr, trpart + blockIdx.x * 4 + (threadIdx.x >> 6), lane);
+    }
 }
 
 // post_kernel for a FRAGMENT-MAJOR product (stream_gemm.hpp, frag_out; H >= 128, un-split pass): the product tile of
@@ -147,13 +201,17 @@ template <int MODE, int NH>
 __global__ __launch_bounds__(256) void post_frag_kernel(const float4* __restrict__ In4, const float* __restrict__ S,
                                                         float* __restrict__ Fac, uint4* __restrict__ Ft,
                                                         const unsigned char* __restrict__ mask, int hmask_start, int XT,
-                                                        const int* __restrict__ stop) {
+                                                        const int* __restrict__ stop, double* __restrict__ trpart = nullptr) {
     constexpr int Hp = NH * 32;
     constexpr int NXT = PostCfg<NH>::NXT;
+    __shared__ float tbuf[4][32 * TB_LD];
     if (stop && *stop) return;
     const int lane = threadIdx.x & 63;
     const int xt0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * NXT;
-    if (xt0 >= XT) return;
+    if (xt0 >= XT) {
+        if (trpart && lane == 0) trpart[blockIdx.x * 4 + (threadIdx.x >> 6)] = 0.0;
+        return;
+    }
     const int c = lane & 31, half = lane >> 5;
 
     f32x16 acc[NXT][NH];
@@ -240,6 +298,27 @@ __global__ __launch_bounds__(256) void post_frag_kernel(const float4* __restrict
             for (int r = 0; r < 16; ++r) Fac[(x0 + rho(r, half)) * Hp + hcol] = acc[i][h][r];
         }
     }
+    if (trpart) {                                            // tr(B'YA): the product fragments again (L2-hot), block by block
+        double tr = 0.0;
+        float* tb = tbuf[threadIdx.x >> 6];
+#pragma unroll
+        for (int i = 0; i < NXT; ++i) {
+            const int xt = xt0 + i;
+            if (xt >= XT) break;
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                const float4* t4 = In4 + (((long long)xt * NH + h) * 64 + lane) * 4;
+                float q[16];
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const float4 v = t4[qd];
+                    q[4 * qd] = v.x; q[4 * qd + 1] = v.y; q[4 * qd + 2] = v.z; q[4 * qd + 3] = v.w;
+                }
+                tr += (double)tile_dot_qb<true>(q, acc[i][h], tb, lane);
+            }
+        }
+        store_wave_dot(tr, trpart + blockIdx.x * 4 + (threadIdx.x >> 6), lane);
+    }
 }
 
 // ---- the inverse of write_factor_tiles: the fp32 factor values a tile's operand fragments encode (hi + lo) ------
@@ -296,14 +375,14 @@ __global__ __launch_bounds__(256) void untile_factor_kernel(const uint4* __restr
 // q[hin][r] on lane (half, c) holds (Y A)[x0 + c][hin*32 + rho(r, half)] -- the streaming kernel's accumulator as it
 // stands.  An exact-f32 MFMA of k = 2 takes its two k values from the two lane halves, and the contraction may run in
 // any k order as long as both operands agree, so register r IS the A operand of instruction r when the table operand
-// is read in the same permuted order: sperm[hin][r][h] = S[hin*32 + rho(r, half)][h*32 + c].  No store, no reload,
+// is read in the same permuted order: S[hin*32 + rho(r, half)][h*32 + c] (from the workgroup's LDS copy).  No store, no reload,
 // no shuffle between the product and the update B = (Y A) SigmaB / sigma2 (src/vbmf.jl:112).
 template <int MODE, int NH>
-__device__ __forceinline__ void post_gram_tile_regs(const f32x16 (&q)[NH], const float (&sperm)[NH][16][NH], int xt,
+__device__ __forceinline__ void post_gram_tile_regs(const f32x16 (&q)[NH], const float* stab /* LDS: S[Hp][Hp] */, int xt,
                                                     float* __restrict__ Fac, const float* __restrict__ Prev,
                                                     uint4* __restrict__ Ft, int lane,
                                                     f32x16 (&G)[NH * (NH + 1) / 2], f32x16 (&D)[NH * (NH + 1) / 2],
-                                                    const f32x16 (&pv)[NH], int store_fac) {
+                                                    const f32x16 (&pv)[NH], int store_fac, float* tb, double& trd) {
     constexpr int Hp = NH * 32;
     const int c = lane & 31, half = lane >> 5;
     const long long x0 = (long long)xt * 32;
@@ -320,7 +399,7 @@ __device__ __forceinline__ void post_gram_tile_regs(const f32x16 (&q)[NH], const
 #pragma unroll
             for (int h = 0; h < NH; ++h) {
                 const float a = q[hin][t];
-                acc[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, sperm[hin][t][h], acc[h], 0, 0, 0);
+                acc[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, stab[(hin * 32 + rho(t, half)) * Hp + h * 32 + c], acc[h], 0, 0, 0);
             }
     // In the bf16 modes the new tile IS hi + lo, and its operand fragments (lane = column, 8 consecutive k per lane) are
     // both operands of the bf16 MFMA with the row index as k: F'F = hi'hi + hi'lo + lo'hi + lo'lo, every product exact,
@@ -333,6 +412,17 @@ __device__ __forceinline__ void post_gram_tile_regs(const f32x16 (&q)[NH], const
 #pragma unroll
             for (int r = 0; r < 16; ++r) Fac[(x0 + rho(r, half)) * Hp + h * 32 + c] = acc[h][r];
         }
+    }
+    {   // tr(B'YA) of this tile: the product is still in registers, the new factor is now exactly what the tiles encode
+        float tsum = 0.f;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            float qf[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) qf[t] = q[h][t];
+            tsum += tile_dot_qb<true>(qf, acc[h], tb, lane);
+        }
+        trd += (double)tsum;
     }
     if constexpr (MODE == MODE_F32) {
         int p = 0;
@@ -405,11 +495,13 @@ __global__ __launch_bounds__(256) void post_gram_kernel(const float* __restrict_
                                                         float* __restrict__ Fac, const float* __restrict__ Prev,
                                                         uint4* __restrict__ Ft, const unsigned char* __restrict__ mask,
                                                         int hmask_start, int XT, float* __restrict__ slabs,
-                                                        const int* __restrict__ stop) {
+                                                        const int* __restrict__ stop, double* __restrict__ trpart = nullptr) {
     static_assert(NH <= 2, "fused Gram keeps NH(NH+1)/2 pair tiles per matrix in registers");
     constexpr int Hp = NH * 32;
     constexpr int NPAIR = NH * (NH + 1) / 2;
     __shared__ float fold[2 * NPAIR * 16 * 64];
+    __shared__ float tbuf[4][32 * TB_LD];
+    double trd = 0.0;
     if (stop && *stop) return;
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
@@ -492,6 +584,12 @@ __global__ __launch_bounds__(256) void post_gram_kernel(const float* __restrict_
 #pragma unroll
             for (int r = 0; r < 16; ++r) Fac[(x0 + rho(r, half)) * Hp + hcol] = acc[h][r];
         }
+        if (trpart != nullptr) {                             // tr(B'YA) of this tile (B side only)
+            float tsum = 0.f;
+#pragma unroll
+            for (int h = 0; h < NH; ++h) tsum += tile_dot_qb<FRAG>(areg[h], acc[h], tbuf[wib], lane);
+            trd += (double)tsum;
+        }
         // Gram of the new tile: pair index p runs over h1 <= h2
         {
             int p = 0;
@@ -543,20 +641,39 @@ __global__ __launch_bounds__(256) void post_gram_kernel(const float* __restrict_
     }
     float* o = slabs + (long long)blockIdx.x * (2 * NPAIR * 1024);
     for (int i = threadIdx.x; i < 2 * NPAIR * 1024; i += 256) o[i] = fold[i];
+    if (trpart != nullptr) store_wave_dot(trd, trpart + blockIdx.x * 4 + wib, lane);
 }
 
 // fp64 reduction of the post_gram slabs into dense Hp x Hp matrices (both triangles).
 //   one thread per (matrix, pair, reg, lane) x 4 slab groups; LDS fold of the groups.
+// fixed-order sum of the per-wave shares of tr(B'YA) (one block; deterministic: fixed strides, fixed tree)
+__device__ __forceinline__ void fold_wave_dots(const double* __restrict__ trpart, int ntr, double* __restrict__ outTr) {
+    __shared__ double trw[16];
+    double v = 0.0;
+    for (int k = threadIdx.x; k < ntr; k += blockDim.x) v += trpart[k];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if ((threadIdx.x & 63) == 0) trw[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += trw[w];
+        *outTr = t;
+    }
+}
+
 template <int NH>
 __global__ __launch_bounds__(1024) void pair_slab_reduce_kernel(const float* __restrict__ slabs, int nslab,
                                                                 double* __restrict__ outG, double* __restrict__ outD,
-                                                                const int* __restrict__ stop) {
+                                                                const int* __restrict__ stop,
+                                                                const double* __restrict__ trpart = nullptr, int ntr = 0,
+                                                                double* __restrict__ outTr = nullptr) {
     constexpr int Hp = NH * 32;
     constexpr int NPAIR = NH * (NH + 1) / 2;
     constexpr int NOUT = 2 * NPAIR * 1024;
     constexpr int NG = 16;
     __shared__ double part[NG][64];
     if (stop && *stop) return;
+    if (outTr != nullptr && blockIdx.x == gridDim.x - 1) fold_wave_dots(trpart, ntr, outTr);
     const int j = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int idx = blockIdx.x * 64 + j;                       // (mat, pair, r, lane) flat, grid = NOUT/64
     double s = 0.0;
@@ -773,8 +890,11 @@ __global__ __launch_bounds__(256) void gram_tiles_kernel(const uint4* __restrict
 // out[which][i] = sum_chunk slabs[chunk][which][i]  (fp64).  which in {0: Gram, 1: delta-Gram}.
 __global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restrict__ slabs, int nchunk, int n,
                                                           double* __restrict__ outG, double* __restrict__ outD,
-                                                          const int* __restrict__ stop) {
+                                                          const int* __restrict__ stop,
+                                                          const double* __restrict__ trpart = nullptr, int ntr = 0,
+                                                          double* __restrict__ outTr = nullptr) {
     if (stop && *stop) return;
+    if (outTr != nullptr && blockIdx.x == gridDim.x - 1) fold_wave_dots(trpart, ntr, outTr);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 2 * n) return;
     const int which = i / n, j = i % n;

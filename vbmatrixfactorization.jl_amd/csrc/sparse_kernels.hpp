@@ -354,8 +354,7 @@ __global__ __launch_bounds__(256) void colsum_fold_kernel(const double* __restri
     }
 }
 
-// SigmaB = inv(diag(CB) + sigmaHat*(GA + SigmaA));  S32 = sigmaHat*SigmaB;  KB = K/sigmaHat (so that
-// B = Q*S32 gives tr(B'Q) = tr(KB * B'B), the identity the basic model uses too).
+// SigmaB = inv(diag(CB) + sigmaHat*(GA + SigmaA));  S32 = sigmaHat*SigmaB (so that B = Q*S32).
 // s32_unit (diag_var, :256-261): S32 = SigmaB itself; the per-row sigma_l is applied to the rows of B afterwards
 template <int R, int T>
 __global__ __launch_bounds__(T * T) void sparse_cov_b_kernel(double* __restrict__ st, StateLayout lay, int H,
@@ -380,7 +379,6 @@ __global__ __launch_bounds__(T * T) void sparse_cov_b_kernel(double* __restrict_
             if (i < H && j < H) {
                 v = sig * (st[lay.GA() + (long long)i * Hp + j] + st[lay.SA() + (long long)i * Hp + j]);
                 if (i == j) v += cb[i];
-                st[lay.KB() + (long long)i * Hp + j] = v / sig;
             }
             Kg[t] = v;
         }
@@ -404,7 +402,6 @@ __global__ __launch_bounds__(T * T) void sparse_cov_b_kernel(double* __restrict_
                 if (i < H && j < H) {
                     v = sig * (st[lay.GA() + (long long)i * Hp + j] + st[lay.SA() + (long long)i * Hp + j]);
                     if (i == j) v += cb[i];
-                    st[lay.KB() + (long long)i * Hp + j] = v / sig;
                 }
                 w[a][b] = v;
             }
@@ -436,7 +433,7 @@ __global__ __launch_bounds__(T * T) void sparse_cov_b_kernel(double* __restrict_
     if (threadIdx.x == 0) scal[S_LOGDET_SB] = -ld;          // log det SigmaB
 }
 
-// flags: bit1 est_cb -> CB/delta, bit2 sigma update, bit3 d + loop bookkeeping, bit4 tr(B'Q) from the identity
+// flags: bit1 est_cb -> CB/delta, bit2 sigma update, bit3 d + loop bookkeeping (bit4 unused: tr(B'Q) is always st[GX])
 __global__ __launch_bounds__(1024) void sparse_ctrl_end_kernel(double* __restrict__ st, StateLayout lay, int H,
                                                               double Lg, int flags, double eps,
                                                               double* __restrict__ trace, int* __restrict__ ints) {
@@ -447,18 +444,15 @@ __global__ __launch_bounds__(1024) void sparse_ctrl_end_kernel(double* __restric
     const double* GB = st + lay.GB();
     const double* SA = st + lay.SA();
     const double* SB = st + lay.SB();
-    const double* KB = st + lay.KB();
     double* delta = st + lay.ca();
     double* cb = st + lay.cb();
     double* scal = st + lay.scal();
-    double t1 = 0.0, t2 = 0.0;
+    double t2 = 0.0;
     for (int t = threadIdx.x; t < H * H; t += blockDim.x) {
         const int i = t / H, j = t - i * H;
         const long long ij = (long long)i * Hp + j;
-        t1 += KB[ij] * GB[ij];
         t2 += (GA[ij] + SA[ij]) * (GB[ij] + Lg * SB[ij]);        // SigmaA already summed over m (QS3)
     }
-    t1 = block_sum(t1, red);
     t2 = block_sum(t2, red);
     __syncthreads();
     if (flags & 2)
@@ -469,7 +463,7 @@ __global__ __launch_bounds__(1024) void sparse_ctrl_end_kernel(double* __restric
             cb[h] = scal[S_GAMMA] / dl;                                         // :298
         }
     if (threadIdx.x == 0) {
-        const double trBQ = (flags & 16) ? t1 : scal[S_TRDOT];
+        const double trBQ = st[lay.GX()];                        // sum B o (Y A): direct, from the kernel that produced B
         scal[S_TRYBA] = trBQ;
         if (flags & 4) {
             const double zeta = scal[S_ZETA0] + 0.5 * scal[S_TRYY] - trBQ + 0.5 * t2;   // :317-319
@@ -489,14 +483,17 @@ __global__ __launch_bounds__(1024) void sparse_ctrl_end_kernel(double* __restric
     }
 }
 
-// partials[b][0..7] = [ sum log(beta) g0, g1, g2, sum CA*(A^2 + dS), sum CA g0, g1, g2, sum log(dS) ] over the valid
-// M x H entries (groups as in sparse_update_ca_kernel; the one-group sparse model passes H0 = H)
+// partials[b][0..15] = [ sum log(beta) g0, g1, g2, sum' CA*(A^2 + dS), sum CA g0, g1, g2, sum' log(dS),
+//                        count', sum' log(beta), sum' CA, 0... ] over the valid M x H entries (groups as in
+// sparse_update_ca_kernel; the one-group sparse model passes H0 = H).  sum' / count' run over the entries that
+// lowerBoundTrimmed keeps, |A| > trim (src/vbmf_sparse.jl:481); trim < 0 keeps everything (lowerBound).
+constexpr int LB_NS = 16;
 __global__ __launch_bounds__(256) void sparse_lb_sums_kernel(const float* __restrict__ A32, const float* __restrict__ dS32,
                                                              const float* __restrict__ CA32, const float* __restrict__ beta32,
                                                              long long M, int H, int Hp, int H0, long long M0,
-                                                             double* __restrict__ partials) {
-    __shared__ double sh[4][8];
-    double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                                                             double* __restrict__ partials, double trim) {
+    __shared__ double sh[4][LB_NS];
+    double s[LB_NS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const long long total = M * Hp;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
@@ -507,19 +504,22 @@ __global__ __launch_bounds__(256) void sparse_lb_sums_kernel(const float* __rest
         const int g = ca_group(m, h, H0, M0);
         const double lb = log(be);
         if (g == 0) { s[0] += lb; s[4] += ca; } else if (g == 1) { s[1] += lb; s[5] += ca; } else { s[2] += lb; s[6] += ca; }
-        s[3] += ca * (a * a + ds); s[7] += log(ds);
+        if (trim < 0.0 || fabs(a) > trim) {
+            s[3] += ca * (a * a + ds); s[7] += log(ds);
+            s[8] += 1.0; s[9] += lb; s[10] += ca;
+        }
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
+    for (int k = 0; k < LB_NS; ++k)
         for (int off = 32; off > 0; off >>= 1) s[k] += __shfl_down(s[k], off);
     if ((threadIdx.x & 63) == 0) {
         const int w = threadIdx.x >> 6;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) sh[w][k] = s[k];
+        for (int k = 0; k < LB_NS; ++k) sh[w][k] = s[k];
     }
     __syncthreads();
-    if (threadIdx.x < 8)
-        partials[(long long)blockIdx.x * 8 + threadIdx.x] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+    if (threadIdx.x < LB_NS)
+        partials[(long long)blockIdx.x * LB_NS + threadIdx.x] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
 }
 
 // ---- heteroscedastic rows (diag_var = true, src/vbmf_sparse.jl:207-212, 229-230, 256-261, 308-315) ----------

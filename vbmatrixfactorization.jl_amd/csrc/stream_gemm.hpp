@@ -55,9 +55,11 @@ constexpr int Y_AUX = 2;
 struct EpiArgs {
     const float* S; float* Fac; const float* Prev; uint4* Ft; float* slabs;
     const int* sready; int expect;           // expect < 0: the table was complete before the launch
+    int spin_limit;                          // bounded wait for `sready` (polls of ~0.4 us each); on expiry *err = 2
     int* err;
     int store_fac;                           // 0 inside vbmf_run: the fp32 factor is rebuilt from the tiles once, at the end
     int frag_out;                            // EPI = 0 only: write the product in FRAGMENT-MAJOR order (below)
+    double* trpart;                          // EPI = 1: per-wave shares of tr(B'YA) = sum (Y A) o BHat  [4 * workgroups]
 };
 
 // FDBG (tuning harness only): 1 = the factor ring re-reads one L1-hot k-step, 2 = no factor refills at all
@@ -236,23 +238,23 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const uint4* __restric
         constexpr int NPAIR = NH * (NH + 1) / 2;
         constexpr int Hp = NH * 32;
         __shared__ float fold[2 * NPAIR * 16 * 64];
+        __shared__ float tbuf[4][32 * TB_LD];
+        double trd = 0.0;
         const int c = lane & 31, half = lane >> 5;
         if (epi.expect >= 0) {                             // SigmaB / sigma2 is written by workgroup 0 of this launch
             int spins = 0;
             while (__hip_atomic_load(epi.sready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epi.expect) {
                 __builtin_amdgcn_s_sleep(16);
-                if (++spins > (1 << 22)) { if (lane == 0) atomicExch(epi.err, 2); break; }    // never hang the device
+                if (++spins > epi.spin_limit) { if (lane == 0) atomicExch(epi.err, 2); break; }    // never hang the device
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
-        float sperm[NH][16][NH];
-#pragma unroll
-        for (int hin = 0; hin < NH; ++hin)
-#pragma unroll
-            for (int t = 0; t < 16; ++t)
-#pragma unroll
-                for (int h = 0; h < NH; ++h)
-                    sperm[hin][t][h] = epi.S[(long long)(hin * 32 + rho(t, half)) * Hp + h * 32 + c];
+        // the SigmaB / sigma2 table goes to LDS once per workgroup (16-byte loads) and is read from there as the MFMA's B
+        // operand, row rho(t, half) for step t: as 64 registers per lane it pushed the tile body over the register file
+        __shared__ __attribute__((aligned(16))) float stab[Hp * Hp];
+        for (int i = threadIdx.x; i < Hp * Hp / 4; i += 256)
+            reinterpret_cast<float4*>(stab)[i] = reinterpret_cast<const float4*>(epi.S)[i];
+        __syncthreads();
         f32x16 G[NPAIR], D[NPAIR];
 #pragma unroll
         for (int p = 0; p < NPAIR; ++p)
@@ -262,16 +264,24 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const uint4* __restric
             // the previous factor's rows of all this wave's tiles first (they are only needed for the delta-Gram at the
             // end of each tile: one round of memory latency instead of one per tile)
             // read from the factor's OPERAND TILES (they encode exactly the fp32 factor): 1 KiB wave loads
-            f32x16 pv[NXW_][NH];
+            // (one tile ahead, not all NXW at once: with the tr(B'YA) block in the tile body the full prefetch spilled)
+            f32x16 pvn[NH];
 #pragma unroll
-            for (int i = 0; i < NXW_; ++i)
+            for (int h = 0; h < NH; ++h) read_factor_tiles<MODE, NH>(epi.Ft, pvn[h], xg * NXW_, h, lane);
 #pragma unroll
-                for (int h = 0; h < NH; ++h) read_factor_tiles<MODE, NH>(epi.Ft, pv[i][h], xg * NXW_ + i, h, lane);
+            for (int i = 0; i < NXW_; ++i) {
+                f32x16 pvc[NH];
 #pragma unroll
-            for (int i = 0; i < NXW_; ++i)
-                post_gram_tile_regs<MODE, NH>(acc[i], sperm, xg * NXW_ + i, epi.Fac, epi.Prev, epi.Ft, lane, G, D, pv[i],
-                                              epi.store_fac);
+                for (int h = 0; h < NH; ++h) pvc[h] = pvn[h];
+                if (i + 1 < NXW_) {
+#pragma unroll
+                    for (int h = 0; h < NH; ++h) read_factor_tiles<MODE, NH>(epi.Ft, pvn[h], xg * NXW_ + i + 1, h, lane);
+                }
+                post_gram_tile_regs<MODE, NH>(acc[i], stab, xg * NXW_ + i, epi.Fac, epi.Prev, epi.Ft, lane, G, D, pvc,
+                                              epi.store_fac, tbuf[wib], trd);
+            }
         }
+        store_wave_dot(trd, epi.trpart + (long long)xb * 4 + wib, lane);   // (an idle wave contributes 0)
         // fold the four waves' partials (fixed order => deterministic), then one coalesced slab store per workgroup
         for (int wv = 0; wv < 4; ++wv) {
             if (wib == wv) {

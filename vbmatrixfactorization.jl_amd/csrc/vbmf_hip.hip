@@ -60,7 +60,9 @@ struct vbmf_ctx {
     float *SA32 = nullptr, *SB32 = nullptr, *gslab = nullptr;
     int tiles_per_chunk = 32;
     double* st = nullptr;
-    double* gtmp = nullptr;          // 2*Hp^2 local Gram sums (all-reduce staging)
+    double* gtmp = nullptr;          // [B'B | dB'dB | tr(B'YA), pad] local sums: the send side of the packed all-reduce
+    double* trpart = nullptr;        // per-wave shares of tr(B'YA) left by the kernel that produced BHat
+    int trpart_cap = 0, ntr = 0;     // ntr: shares waiting for the next B-side Gram reduction (0: none)
     double* ypart = nullptr;         // per-block partials of ||Y||^2 (fixed-order sum)
     // ARD-sparse variant (src/vbmf_sparse.jl, diagonal branch)
     bool sparse = false;
@@ -105,13 +107,16 @@ struct vbmf_ctx {
     bool P_frag = false;              // the Y'B product in c->P / c->Pred is fragment-major (stream_gemm.hpp, frag_out)
     bool B32_stale = false;           // the register epilogue skipped the fp32 store of B (inside vbmf_run): tiles are current
     int sready_seq = 0;               // sequence number of the Sigma-table release flag (register epilogue)
+    int epi_spin_limit = 1 << 22;     // bounded wait of the register epilogue for that flag (~2 s), then VBMF_ERR_SYNC
+    int epi_expect_skew = 0;          // test hook (vbmf_debug_set): makes the epilogue wait for a sequence number nobody publishes
     int64_t ends_enqueued = 0;        // sweeps whose closing control step has been enqueued in this run (trace row)
     bool tail_pending = false;        // eig + ctrl_end of the last enqueued sweep not issued yet
     int run_flags = 0;
     double run_eps = 0.0;
     double* run_trace = nullptr;
     bool haveY = false, haveState = false;
-    bool gA_valid = false, gB_valid = false, P_valid = false, kb_identity = false;
+    bool gA_valid = false, gB_valid = false, P_valid = false;
+    bool tr_valid = false;            // st[GX] = tr(B'YA) of the current (AHat, BHat)
     double trYY_local = 0.0;
     bool trYY_reduced = true;
     int prof = 0;                     // 0 off; k: HIP events around every k-th launch of each pass
@@ -315,8 +320,11 @@ static int launch_stream(vbmf_ctx* c, int pass, int ctrl_mode = 0, bool epi = fa
     if (epi) {
         c->sready_seq = (c->sready_seq + 1) & 0x3fffffff;
         ea.S = c->SB32; ea.Fac = c->B32[c->bcur ^ 1]; ea.Prev = c->B32[c->bcur]; ea.Ft = c->FB; ea.slabs = c->gslab;
-        ea.sready = c->ints + I_SREADY; ea.expect = ctrl_mode ? c->sready_seq : -1; ea.err = c->ints + I_ERR;
+        ea.sready = c->ints + I_SREADY; ea.expect = ctrl_mode ? c->sready_seq + c->epi_expect_skew : -1; ea.err = c->ints + I_ERR;
+        ea.spin_limit = c->epi_spin_limit;
         ea.store_fac = c->in_run ? 0 : 1;
+        ea.trpart = c->trpart;
+        c->ntr = 4 * bps;
         if (c->in_run) c->B32_stale = true;
         if (ctrl_mode) { ca.sready = c->ints + I_SREADY; ca.sready_val = c->sready_seq; }
         if (epi_slabs) *epi_slabs = bps;
@@ -359,16 +367,22 @@ static int launch_stream(vbmf_ctx* c, int pass, int ctrl_mode = 0, bool epi = fa
     return VBMF_OK;
 }
 
-// sum all-reduce of a device buffer over the ranks, in place, ordered on the context's stream
-static int allreduce_sum(vbmf_ctx* c, void* buf, size_t count, bool is_double) {
+// recv = sum over the ranks of send (recv == send: in place), ordered on the context's stream.
+// The two per-sweep reductions are OUT OF PLACE on purpose: their send buffers are written by stop-gated kernels only, so a
+// sweep enqueued after the device-side stop re-reduces the SAME partials into the SAME result -- the frozen state stays
+// frozen without a staging buffer and a gated copy behind every collective (one launch fewer per sweep).
+static int allreduce_sum(vbmf_ctx* c, const void* send, void* recv, size_t count, bool is_double) {
     if (c->ar_hook) {
-        const int rc = c->ar_hook(c->ar_user, buf, count, is_double ? 1 : 0, (void*)c->stream);
+        if (send != recv)
+            HIPCHK(c, hipMemcpyAsync(recv, send, count * (is_double ? 8 : 4), hipMemcpyDeviceToDevice, c->stream));
+        const int rc = c->ar_hook(c->ar_user, recv, count, is_double ? 1 : 0, (void*)c->stream);
         if (rc != 0) FAIL(c, VBMF_ERR_COMM, "all-reduce transport hook failed (%d)", rc);
         return VBMF_OK;
     }
-    NCCLCHK(c, ncclAllReduce(buf, buf, count, is_double ? ncclDouble : ncclFloat, ncclSum, c->comm, c->stream));
+    NCCLCHK(c, ncclAllReduce(send, recv, count, is_double ? ncclDouble : ncclFloat, ncclSum, c->comm, c->stream));
     return VBMF_OK;
 }
+static int allreduce_sum(vbmf_ctx* c, void* buf, size_t count, bool is_double) { return allreduce_sum(c, buf, buf, count, is_double); }
 
 static int launch_post(vbmf_ctx* c, int which, const float* In, int nslab) {
     const Dims& d = which == 0 ? c->d1 : c->d2;
@@ -381,9 +395,11 @@ static int launch_post(vbmf_ctx* c, int which, const float* In, int nslab) {
     const int hstart = (int)(c->H - c->H1);
     const int nxt = c->NH >= 8 ? 2 : 1;                          // = PostCfg<NH>::NXT
     const int grid = (cdiv(d.XT, nxt) + 3) / 4;
+    double* trp = (which == 1 && !c->diagvar && 4 * grid <= c->trpart_cap) ? c->trpart : nullptr;   // (diag_var rescales the rows afterwards)
+    c->ntr = trp ? 4 * grid : 0;
     DISPATCH_MODE(c->mode, DISPATCH_NH(c->NH, {
         hipLaunchKernelGGL((post_kernel<MODEc, NHc>), dim3(grid), dim3(256), 0, c->stream, In, ld, nslab, slabStride, S,
-                           Fac, Ft, mk, hstart, d.XT, c->ints + I_STOP);
+                           Fac, Ft, mk, hstart, d.XT, c->ints + I_STOP, trp);
     }));
     HIPCHK(c, hipGetLastError());
     return VBMF_OK;
@@ -392,16 +408,18 @@ static int launch_post(vbmf_ctx* c, int which, const float* In, int nslab) {
 // fused post + Gram (+ delta-Gram) for NH <= 2; reduction into the state block (or the all-reduce staging)
 static bool fused_gram(const vbmf_ctx* c) { return c->NH <= 2; }
 
-static int launch_pair_reduce(vbmf_ctx* c, int which, int nslab);
+static int launch_pair_reduce(vbmf_ctx* c, int which, int nslab, int ntr = 0);
 
 // B from a fragment-major product (H >= 128, un-split Y*A pass)
 static int launch_post_frag(vbmf_ctx* c) {
     const Dims& d = c->d2;
     const int nxt = c->NH >= 8 ? 2 : 1;                          // = PostCfg<NH>::NXT
     const int grid = (cdiv(d.XT, nxt) + 3) / 4;
+    double* trp = (!c->diagvar && 4 * grid <= c->trpart_cap) ? c->trpart : nullptr;
+    c->ntr = trp ? 4 * grid : 0;
     DISPATCH_MODE(c->mode, {
-        if (c->NH == 4) hipLaunchKernelGGL((post_frag_kernel<MODEc, 4>), dim3(grid), dim3(256), 0, c->stream, (const float4*)c->Q, c->SB32, c->B32[c->bcur ^ 1], c->FB, (const unsigned char*)nullptr, 0, d.XT, c->ints + I_STOP);
-        else hipLaunchKernelGGL((post_frag_kernel<MODEc, 8>), dim3(grid), dim3(256), 0, c->stream, (const float4*)c->Q, c->SB32, c->B32[c->bcur ^ 1], c->FB, (const unsigned char*)nullptr, 0, d.XT, c->ints + I_STOP);
+        if (c->NH == 4) hipLaunchKernelGGL((post_frag_kernel<MODEc, 4>), dim3(grid), dim3(256), 0, c->stream, (const float4*)c->Q, c->SB32, c->B32[c->bcur ^ 1], c->FB, (const unsigned char*)nullptr, 0, d.XT, c->ints + I_STOP, trp);
+        else hipLaunchKernelGGL((post_frag_kernel<MODEc, 8>), dim3(grid), dim3(256), 0, c->stream, (const float4*)c->Q, c->SB32, c->B32[c->bcur ^ 1], c->FB, (const unsigned char*)nullptr, 0, d.XT, c->ints + I_STOP, trp);
     });
     HIPCHK(c, hipGetLastError());
     return VBMF_OK;
@@ -418,34 +436,34 @@ static int launch_post_gram(vbmf_ctx* c, int which, const float* In, int nslab, 
     const int hstart = (int)(c->H - c->H1);
     const int grid = std::min(256, (d.XT + 3) / 4);
     const int* stop = c->ints + I_STOP;
+    double* trp = (which == 1 && !c->diagvar) ? c->trpart : nullptr;
     DISPATCH_MODE(c->mode, {
         if (frag) {
-            if (c->NH == 1) hipLaunchKernelGGL((post_gram_kernel<MODEc, 1, true>), dim3(grid), dim3(256), 0, c->stream, In, ld, nslab, slabStride, S, Fac, Prev, Ft, mk, hstart, d.XT, c->gslab, stop);
-            else hipLaunchKernelGGL((post_gram_kernel<MODEc, 2, true>), dim3(grid), dim3(256), 0, c->stream, In, ld, nslab, slabStride, S, Fac, Prev, Ft, mk, hstart, d.XT, c->gslab, stop);
+            if (c->NH == 1) hipLaunchKernelGGL((post_gram_kernel<MODEc, 1, true>), dim3(grid), dim3(256), 0, c->stream, In, ld, nslab, slabStride, S, Fac, Prev, Ft, mk, hstart, d.XT, c->gslab, stop, trp);
+            else hipLaunchKernelGGL((post_gram_kernel<MODEc, 2, true>), dim3(grid), dim3(256), 0, c->stream, In, ld, nslab, slabStride, S, Fac, Prev, Ft, mk, hstart, d.XT, c->gslab, stop, trp);
         } else {
-            if (c->NH == 1) hipLaunchKernelGGL((post_gram_kernel<MODEc, 1>), dim3(grid), dim3(256), 0, c->stream, In, ld, nslab, slabStride, S, Fac, Prev, Ft, mk, hstart, d.XT, c->gslab, stop);
-            else hipLaunchKernelGGL((post_gram_kernel<MODEc, 2>), dim3(grid), dim3(256), 0, c->stream, In, ld, nslab, slabStride, S, Fac, Prev, Ft, mk, hstart, d.XT, c->gslab, stop);
+            if (c->NH == 1) hipLaunchKernelGGL((post_gram_kernel<MODEc, 1>), dim3(grid), dim3(256), 0, c->stream, In, ld, nslab, slabStride, S, Fac, Prev, Ft, mk, hstart, d.XT, c->gslab, stop, trp);
+            else hipLaunchKernelGGL((post_gram_kernel<MODEc, 2>), dim3(grid), dim3(256), 0, c->stream, In, ld, nslab, slabStride, S, Fac, Prev, Ft, mk, hstart, d.XT, c->gslab, stop, trp);
         }
     });
-    return launch_pair_reduce(c, which, grid);
+    return launch_pair_reduce(c, which, grid, trp ? 4 * grid : 0);
 }
 
 // fp64 reduction of `nslab` workgroup slabs of Gram partials in c->gslab into the state (all-reduced when row-sharded)
-static int launch_pair_reduce(vbmf_ctx* c, int which, int nslab) {
+static int launch_pair_reduce(vbmf_ctx* c, int which, int nslab, int ntr) {
     const int* stop = c->ints + I_STOP;
     const int n = c->Hp * c->Hp;
     const bool shard = (which == 1 && sharded(c));
     double* outG = shard ? c->gtmp : c->st + (which == 0 ? c->lay.GA() : c->lay.GB());
     double* outD = which == 0 ? nullptr : (shard ? c->gtmp + n : c->st + c->lay.GD());
-    if (c->NH == 1) hipLaunchKernelGGL((pair_slab_reduce_kernel<1>), dim3(2 * 1 * 1024 / 64), dim3(1024), 0, c->stream, c->gslab, nslab, outG, outD, stop);
-    else hipLaunchKernelGGL((pair_slab_reduce_kernel<2>), dim3(2 * 3 * 1024 / 64), dim3(1024), 0, c->stream, c->gslab, nslab, outG, outD, stop);
+    double* outTr = (which == 1 && ntr > 0) ? (shard ? c->gtmp + 2 * n : c->st + c->lay.GX()) : nullptr;
+    if (c->NH == 1) hipLaunchKernelGGL((pair_slab_reduce_kernel<1>), dim3(2 * 1 * 1024 / 64), dim3(1024), 0, c->stream, c->gslab, nslab, outG, outD, stop, c->trpart, ntr, outTr);
+    else hipLaunchKernelGGL((pair_slab_reduce_kernel<2>), dim3(2 * 3 * 1024 / 64), dim3(1024), 0, c->stream, c->gslab, nslab, outG, outD, stop, c->trpart, ntr, outTr);
     HIPCHK(c, hipGetLastError());
     if (shard) {
         if (!c->comm_ready) FAIL(c, VBMF_ERR_COMM, "nranks > 1 but vbmf_comm_init was not called");
-        TRY(allreduce_sum(c, c->gtmp, 2 * (size_t)n, true));
-        hipLaunchKernelGGL(gated_copy_kernel, dim3((2 * n + 255) / 256), dim3(256), 0, c->stream, c->gtmp,
-                           c->st + c->lay.GB(), 2 * n, stop);
-        HIPCHK(c, hipGetLastError());
+        // [B'B | dB'dB | tr(B'YA)] in one message, straight into the state block (GB, GD, GX are contiguous)
+        TRY(allreduce_sum(c, c->gtmp, c->st + c->lay.GB(), 2 * (size_t)n + 1, true));
     }
     return VBMF_OK;
 }
@@ -467,7 +485,7 @@ static int launch_retile(vbmf_ctx* c, int which, bool gated = false) {
 }
 
 // Gram of A (which=0) or of B with optional delta-Gram against prev (which=1) into the state block.
-static int launch_gram(vbmf_ctx* c, int which, const float* cur, const float* prev, bool gated) {
+static int launch_gram(vbmf_ctx* c, int which, const float* cur, const float* prev, bool gated, int ntr = 0) {
     const Dims& d = which == 0 ? c->d1 : c->d2;
     const int nchunk = cdiv(d.XT, c->tiles_per_chunk);
     const int nw = nchunk * c->NH * c->NH;
@@ -498,16 +516,19 @@ static int launch_gram(vbmf_ctx* c, int which, const float* cur, const float* pr
     const bool shard = (which == 1 && sharded(c));
     double* outG = shard ? c->gtmp : c->st + (which == 0 ? c->lay.GA() : c->lay.GB());
     double* outD = which == 0 ? nullptr : (shard ? c->gtmp + n : c->st + c->lay.GD());
+    double* outTr = (which == 1 && ntr > 0) ? (shard ? c->gtmp + 2 * n : c->st + c->lay.GX()) : nullptr;
     hipLaunchKernelGGL(gram_reduce_kernel, dim3((2 * n + 255) / 256), dim3(256), 0, c->stream, c->gslab, nchunk, n,
-                       outG, outD, stop);
+                       outG, outD, stop, c->trpart, ntr, outTr);
     HIPCHK(c, hipGetLastError());
     if (shard) {
         if (!c->comm_ready) FAIL(c, VBMF_ERR_COMM, "nranks > 1 but vbmf_comm_init was not called");
-        TRY(allreduce_sum(c, c->gtmp, 2 * (size_t)n, true));
-        // gated copy into the state (after `stop` the state must stay frozen)
-        hipLaunchKernelGGL(gated_copy_kernel, dim3((2 * n + 255) / 256), dim3(256), 0, c->stream, c->gtmp,
-                           c->st + c->lay.GB(), 2 * n, stop);
-        HIPCHK(c, hipGetLastError());
+        if (!gated) {
+            // an un-gated Gram (ensure_gram_B: state just set, no sweep has run) leaves the other two parts of the
+            // message alone: reduce the Gram only
+            TRY(allreduce_sum(c, c->gtmp, c->st + c->lay.GB(), (size_t)n, true));
+        } else {
+            TRY(allreduce_sum(c, c->gtmp, c->st + c->lay.GB(), 2 * (size_t)n + 1, true));
+        }
     }
     return VBMF_OK;
 }
@@ -661,11 +682,13 @@ static int do_update_A(vbmf_ctx* c, bool reuse_P = false) {
             if (commit_pending)
                 sc = SideCopy{c->st + c->lay.W0(), c->st + c->lay.SA(), c->lay.n2(), c->st + c->lay.scal() + S_LOGDET_SA_SHADOW,
                               c->st + c->lay.scal() + S_LOGDET_SA};
+            // row-sharded: this rank's sum stays in slab 0 (written by stop-gated kernels only) and the all-reduce goes
+            // out of place into Pred (see allreduce_sum)
             hipLaunchKernelGGL(slab_sum_kernel, dim3(grid_for(n / 4, 256, 2048)), dim3(256), 0, c->stream, c->P, c->d1.nsplit, n,
-                               c->Pred, n, c->ints + I_STOP, sc);
+                               sharded(c) ? c->P : c->Pred, n, c->ints + I_STOP, sc);
             HIPCHK(c, hipGetLastError());
             if (sharded(c))
-                TRY(allreduce_sum(c, c->Pred, (size_t)n, false));
+                TRY(allreduce_sum(c, c->P, c->Pred, (size_t)n, false));
         }
         TRY(side_join(c));
         if (fused_gram(c)) TRY(launch_post_gram(c, 0, c->Pred, 1, c->P_frag));
@@ -678,7 +701,7 @@ static int do_update_A(vbmf_ctx* c, bool reuse_P = false) {
     if (!fused_gram(c)) TRY(launch_gram(c, 0, c->A32, nullptr, true));
     c->gA_valid = true;
     c->P_valid = true;
-    c->kb_identity = false;
+    c->tr_valid = false;
     return VBMF_OK;
 }
 
@@ -705,11 +728,11 @@ static int do_update_B(vbmf_ctx* c) {
             TRY(launch_ctrl_cov(c, 1));
             TRY(launch_stream(c, 1, 0, true, &nslab));
         }
-        TRY(launch_pair_reduce(c, 1, nslab));
+        TRY(launch_pair_reduce(c, 1, nslab, c->ntr));
         c->bcur ^= 1;
         c->gB_valid = true;
         c->P_valid = false;
-        c->kb_identity = true;
+        c->tr_valid = true;
         return VBMF_OK;
     }
     // H >= 128, un-split pass: the product travels fragment-major (16-byte accesses on both sides)
@@ -733,19 +756,20 @@ static int do_update_B(vbmf_ctx* c) {
     } else {
         if (fragq) TRY(launch_post_frag(c));
         else TRY(launch_post(c, 1, c->Q, 1));
-        TRY(launch_gram(c, 1, c->B32[c->bcur ^ 1], c->B32[c->bcur], true));
+        TRY(launch_gram(c, 1, c->B32[c->bcur ^ 1], c->B32[c->bcur], true, c->ntr));
     }
     c->bcur ^= 1;
     c->gB_valid = true;
     c->P_valid = false;
-    c->kb_identity = true;
+    c->tr_valid = true;
     return VBMF_OK;
 }
 
-// make scal[S_TRDOT] = tr(Y'BA') when the Gram identity is not available; returns the ctrl_end flag
+// make st[GX] = tr(Y'BA') when the last B update did not leave it (state set by the caller, A changed since); *flag: legacy, 0
 static int prepare_trYBA(vbmf_ctx* c, int* flag) {
-    if (c->kb_identity) { *flag = 16; return VBMF_OK; }
-    double* dst = c->st + c->lay.scal() + S_TRDOT;
+    *flag = 0;
+    if (c->tr_valid) return VBMF_OK;
+    double* dst = c->st + c->lay.GX();
     HIPCHK(c, hipMemsetAsync(dst, 0, sizeof(double), c->stream));
     if (c->P_valid) {
         const float* In = (sharded(c) || c->d1.nsplit > 1) ? c->Pred : c->P;
@@ -761,17 +785,27 @@ static int prepare_trYBA(vbmf_ctx* c, int* flag) {
         if (sharded(c)) TRY(allreduce_sum(c, dst, 1, true));
     }
     HIPCHK(c, hipGetLastError());
-    *flag = 0;
+    c->tr_valid = true;
     return VBMF_OK;
+}
+
+// I_ERR on the device: 1 = a pivot of an H x H inverse was non-positive / non-finite, 2 = the register epilogue's bounded
+// wait for the SigmaB table of its own launch gave up (stream_gemm.hpp)
+static int device_err_status(vbmf_ctx* c, int e) {
+    if (e == 2)
+        FAIL(c, VBMF_ERR_SYNC, "in-launch hand-off timed out: the Y*A pass's register epilogue gave up waiting for the SigmaB "
+                               "table of its own launch (bounded spin); this sweep's state is not valid");
+    FAIL(c, VBMF_ERR_NUMERIC, "non-positive or non-finite pivot while inverting an H x H posterior precision");
 }
 
 static int check_device_err(vbmf_ctx* c) {
     HIPCHK(c, hipMemcpyAsync(c->ints_host, c->ints, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->ints_host[I_ERR]) {
+        const int e = c->ints_host[I_ERR];
         int zero = 0;
         hipMemcpy(c->ints + I_ERR, &zero, sizeof(int), hipMemcpyHostToDevice);
-        FAIL(c, VBMF_ERR_NUMERIC, "non-positive or non-finite pivot while inverting an H x H posterior precision");
+        return device_err_status(c, e);
     }
     return VBMF_OK;
 }
@@ -812,7 +846,7 @@ int vbmf_destroy(vbmf_ctx* c) {
     prof_harvest(c);
     if (c->comm) ncclCommDestroy(c->comm);
     void* bufs[] = {c->Y1, c->Y2, c->FA_alloc, c->FB_alloc, c->P, c->Q, c->Pred, c->A32, c->B32[0], c->B32[1], c->SA32,
-                    c->SB32, c->gslab, c->st, c->gtmp, c->ypart, c->ints, c->mask, c->dS32, c->CA32, c->beta32, c->vtab,
+                    c->SB32, c->gslab, c->st, c->gtmp, c->ypart, c->trpart, c->ints, c->mask, c->dS32, c->CA32, c->beta32, c->vtab,
                     c->sigv, c->zetav, c->yrow, c->hpart, c->vsq, c->sig32, c->G32, c->FBs_alloc, c->gpart, c->fpart};
     for (void* b : bufs) if (b) hipFree(b);
     if (c->ints_host) hipHostFree(c->ints_host);
@@ -943,7 +977,9 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
         ALLOC(c->gslab, std::max((size_t)nchunk * 2 * c->Hp * c->Hp * 4, (size_t)c->gslab_cap * 2 * 3 * 1024 * 4));
     }
     ALLOC(c->st, (size_t)c->lay.total() * 8);
-    ALLOC(c->gtmp, (size_t)2 * c->Hp * c->Hp * 8);
+    ALLOC(c->gtmp, ((size_t)2 * c->Hp * c->Hp + 8) * 8);
+    c->trpart_cap = 4 * std::max(c->gslab_cap, (c->d2.XT + 3) / 4 + 1);
+    ALLOC(c->trpart, (size_t)c->trpart_cap * 8);
     ALLOC(c->ypart, (size_t)16384 * 8);
     ALLOC(c->ints, 16 * sizeof(int));
     ALLOC(c->mask, (size_t)c->Mp);
@@ -1030,7 +1066,7 @@ static int finish_Y(vbmf_ctx* c) {
     c->haveY = true;
     c->P_valid = false;
     c->Q_valid = false;
-    c->kb_identity = false;
+    c->tr_valid = false;
     if (c->diagvar) {                                  // ||Y_l||^2 of every row (:310), from the stored values
         DISPATCH_MODE(c->mode, {
             constexpr int TM = (MODEc == MODE_F32) ? MODE_F32 : MODE_BF16;
@@ -1278,7 +1314,7 @@ int vbmf_set_state(vbmf_ctx* c, const double* AHat, int64_t ldA, const double* B
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemsetAsync(c->ints, 0, 16 * sizeof(int), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->gA_valid = c->gB_valid = c->P_valid = c->kb_identity = false;
+    c->gA_valid = c->gB_valid = c->P_valid = c->tr_valid = false;
     c->B32_stale = false;
     c->haveState = true;
     return VBMF_OK;
@@ -1327,7 +1363,7 @@ int vbmf_step(vbmf_ctx* c, int which) {
         flags |= 4 | f;
     }
     if (flags) {
-        if (!(flags & 4)) { TRY(ensure_gram_A(c)); TRY(ensure_gram_B(c)); flags |= c->kb_identity ? 16 : 0; }
+        if (!(flags & 4)) { TRY(ensure_gram_A(c)); TRY(ensure_gram_B(c)); flags |= c->tr_valid ? 16 : 0; }
         TRY(launch_ctrl_end(c, flags, 0.0, nullptr));
     }
     return check_device_err(c);
@@ -1459,14 +1495,14 @@ int vbmf_run(vbmf_ctx* c, int64_t niter, double eps, int est_covs, int est_var, 
         if (trace && done > 0) {
             if (hipMemcpy(trace, trace_dev, (size_t)done * 4 * 8, hipMemcpyDeviceToHost) != hipSuccess) { c->err = "trace copy failed"; rc = VBMF_ERR_HIP; }
         }
-        if (c->ints_host[I_ERR]) { c->err = "non-positive or non-finite pivot while inverting an H x H posterior precision"; rc = VBMF_ERR_NUMERIC; }
+        if (c->ints_host[I_ERR]) rc = device_err_status(c, c->ints_host[I_ERR]);
     }
     int zero4[4] = {0, 0, 0, 0};
     hipMemcpy(c->ints, zero4, sizeof zero4, hipMemcpyHostToDevice);
     if (trace_dev) hipFree(trace_dev);
     c->gA_valid = c->gB_valid = true;
     c->P_valid = false;
-    c->kb_identity = true;
+    c->tr_valid = true;
     return rc;
 }
 
@@ -1585,7 +1621,7 @@ int vbmf_debug_peek(vbmf_ctx* c, int what, uint32_t* out, int64_t nwords, int64_
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (what == VBMF_PEEK_DIMS) {
         const int v[16] = {c->Hp, c->NH, c->mode, c->d1.XT, c->d1.KS, c->d1.nsplit, c->d1.steps_per_split,
-                           c->d2.XT, c->d2.KS, c->d2.nsplit, c->d2.steps_per_split, c->kstep, c->npart, 0, 0, 0};
+                           c->d2.XT, c->d2.KS, c->d2.nsplit, c->d2.steps_per_split, c->kstep, c->npart, c->narrow ? 1 : 0, 0, 0};
         memcpy(out, v, sizeof(int) * (size_t)std::min<int64_t>(16, nwords));
         return VBMF_OK;
     }
@@ -1635,6 +1671,20 @@ int vbmf_debug_time_pass(vbmf_ctx* c, int pass, int iters, double* ms) {
     c->P_valid = false;
     *ms = t / iters;
     return rc;
+}
+
+int vbmf_debug_set(vbmf_ctx* c, int what, int64_t value) {
+    if (!c) return VBMF_ERR_INVALID;
+    switch (what) {
+        case VBMF_DEBUG_EPI_SPIN_LIMIT:
+            if (value < 1 || value > (1ll << 30)) FAIL(c, VBMF_ERR_INVALID, "vbmf_debug_set: spin limit out of range");
+            c->epi_spin_limit = (int)value;
+            return VBMF_OK;
+        case VBMF_DEBUG_EPI_EXPECT_SKEW:
+            c->epi_expect_skew = value ? 1 : 0;
+            return VBMF_OK;
+        default: FAIL(c, VBMF_ERR_INVALID, "vbmf_debug_set: unknown knob");
+    }
 }
 
 int vbmf_device_sync(vbmf_ctx* c) {
@@ -1709,8 +1759,9 @@ static int do_sparse_update_A(vbmf_ctx* c, bool reuse_P = false) {
     if (!(reuse_P && c->P_valid)) {
         TRY(launch_stream(c, 0));
         const long long n = (long long)c->Hp * c->d1.XT * 32;
-        hipLaunchKernelGGL(slab_sum_kernel, dim3(grid_for(n / 4, 256, 2048)), dim3(256), 0, c->stream, c->P, c->d1.nsplit, n, c->Pred, n, stop, SideCopy{});
-        if (sharded(c)) TRY(allreduce_sum(c, c->Pred, (size_t)n, false));      // Y'B summed over the row shards
+        hipLaunchKernelGGL(slab_sum_kernel, dim3(grid_for(n / 4, 256, 2048)), dim3(256), 0, c->stream, c->P, c->d1.nsplit, n,
+                           sharded(c) ? c->P : c->Pred, n, stop, SideCopy{});
+        if (sharded(c)) TRY(allreduce_sum(c, c->P, c->Pred, (size_t)n, false));      // Y'B summed over the row shards (out of place)
     }
     TRY(side_join(c));                              // the previous sweep's lambda_max / CB / sigma / stop test (side stream)
     if (c->full_cov) {
@@ -1726,7 +1777,7 @@ static int do_sparse_update_A(vbmf_ctx* c, bool reuse_P = false) {
         c->gA_valid = true;
         c->P_valid = true;
         c->Q_valid = false;
-        c->kb_identity = false;
+        c->tr_valid = false;
         return VBMF_OK;
     }
     hipLaunchKernelGGL(sparse_v_kernel, dim3((c->Hp + 63) / 64), dim3(64), 0, c->stream, c->st, c->lay, (int)c->H, (double)c->Lg, c->vtab,
@@ -1744,7 +1795,7 @@ static int do_sparse_update_A(vbmf_ctx* c, bool reuse_P = false) {
     c->gA_valid = true;
     c->P_valid = !c->diagvar;
     c->Q_valid = false;
-    c->kb_identity = false;
+    c->tr_valid = false;
     return VBMF_OK;
 }
 
@@ -1768,13 +1819,13 @@ static int do_sparse_update_B(vbmf_ctx* c) {
         else TRY(launch_post(c, 1, c->Q, 1));
         // :261 -- B = diag(sigmaVecHat) * Y A SigmaB: the post kernel applied SigmaB, the rows are scaled here
         if (c->diagvar) TRY(launch_retile_ex(c, 1, c->B32[c->bcur ^ 1], c->FB, c->sig32, 1, true));
-        TRY(launch_gram(c, 1, c->B32[c->bcur ^ 1], c->B32[c->bcur], true));
+        TRY(launch_gram(c, 1, c->B32[c->bcur ^ 1], c->B32[c->bcur], true, c->ntr));
     }
     c->bcur ^= 1;
     c->gB_valid = true;
     c->P_valid = false;
     c->Q_valid = true;
-    c->kb_identity = !c->diagvar;
+    c->tr_valid = !c->diagvar;
     return VBMF_OK;
 }
 
@@ -1906,7 +1957,7 @@ int vbmf_sparse_set_state(vbmf_ctx* c, const double* ATVecHat, const double* dia
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemsetAsync(c->ints, 0, 16 * sizeof(int), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->gA_valid = c->gB_valid = c->P_valid = c->kb_identity = false;
+    c->gA_valid = c->gB_valid = c->P_valid = c->tr_valid = false;
     c->Q_valid = false;
     c->have_noise = false;
     c->haveState = true;
@@ -2064,7 +2115,7 @@ static int sparse_run_impl(vbmf_ctx* c, int64_t niter, double eps, int est_cb, i
     c->gA_valid = c->gB_valid = true;
     c->P_valid = false;
     c->Q_valid = false;
-    c->kb_identity = !c->diagvar;
+    c->tr_valid = !c->diagvar;
     return rc;
 }
 
@@ -2098,7 +2149,7 @@ int vbmf_sparse_set_SigmaA(vbmf_ctx* c, const double* SigmaA) {
     HIPCHK(c, hipSetDevice(c->o.device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     TRY(upload_small(c, SigmaA, c->lay.SA(), true));
-    c->kb_identity = false;
+    c->tr_valid = false;
     return VBMF_OK;
 }
 
@@ -2213,7 +2264,10 @@ int vbmf_sparse_get_noise_rows(vbmf_ctx* c, double* sigmaVecHat, double* zetaVec
     return VBMF_OK;
 }
 
-int vbmf_sparse_lower_bound(vbmf_ctx* c, int clamp, double* lb) {
+}  // extern "C"
+
+// trim < 0: lowerBound; trim >= 0: lowerBoundTrimmed
+static int sparse_lower_bound_impl(vbmf_ctx* c, int clamp, double trim, double* lb) {
     if (!c || !lb) return VBMF_ERR_INVALID;
     if (!c->sparse) FAIL(c, VBMF_ERR_INVALID, "not a sparse context");
     if (c->diagvar) FAIL(c, VBMF_ERR_UNSUPPORTED, "lowerBound is defined for the homoscedastic model only (src/vbmf_sparse.jl:435)");
@@ -2226,20 +2280,27 @@ int vbmf_sparse_lower_bound(vbmf_ctx* c, int clamp, double* lb) {
     TRY(launch_sparse_ctrl_end(c, f, 0.0, nullptr));       // no updates: stores tr(B'YA) in S_TRYBA
     const int nb = 256;
     hipLaunchKernelGGL(sparse_lb_sums_kernel, dim3(nb), dim3(256), 0, c->stream, c->A32, c->dS32, c->CA32, c->beta32,
-                       (long long)c->M, (int)c->H, c->Hp, (int)(c->dual ? c->H0 : c->H), (long long)(c->dual ? c->M0 : c->M), c->ypart);
+                       (long long)c->M, (int)c->H, c->Hp, (int)(c->dual ? c->H0 : c->H), (long long)(c->dual ? c->M0 : c->M), c->ypart, trim);
     HIPCHK(c, hipGetLastError());
-    std::vector<double> part((size_t)nb * 8), buf((size_t)c->lay.total());
+    std::vector<double> part((size_t)nb * LB_NS), buf((size_t)c->lay.total());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(part.data(), c->ypart, part.size() * 8, hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(buf.data(), c->st, buf.size() * 8, hipMemcpyDeviceToHost));
-    double s_logbeta_g[3] = {0, 0, 0}, s_ca_g[3] = {0, 0, 0}, s_caq = 0, s_logds = 0;
+    double s_logbeta_g[3] = {0, 0, 0}, s_ca_g[3] = {0, 0, 0}, s_caq = 0, s_logds = 0, n_keep = 0, s_logbeta_keep = 0, s_ca_keep = 0;
     for (int b = 0; b < nb; ++b) {
-        for (int g = 0; g < 3; ++g) { s_logbeta_g[g] += part[8 * b + g]; s_ca_g[g] += part[8 * b + 4 + g]; }
-        s_caq += part[8 * b + 3]; s_logds += part[8 * b + 7];
+        for (int g = 0; g < 3; ++g) { s_logbeta_g[g] += part[LB_NS * b + g]; s_ca_g[g] += part[LB_NS * b + 4 + g]; }
+        s_caq += part[LB_NS * b + 3]; s_logds += part[LB_NS * b + 7];
+        n_keep += part[LB_NS * b + 8]; s_logbeta_keep += part[LB_NS * b + 9]; s_ca_keep += part[LB_NS * b + 10];
+    }
+    const bool trimmed = trim >= 0.0;
+    if (trimmed && !c->dual) {            // src/vbmf_sparse.jl:482-486: beta and CA are trimmed with ATVecHat (one group)
+        s_logbeta_g[0] = s_logbeta_keep; s_logbeta_g[1] = s_logbeta_g[2] = 0.0;
+        s_ca_g[0] = s_ca_keep; s_ca_g[1] = s_ca_g[2] = 0.0;
     }
     const double s_logbeta = s_logbeta_g[0] + s_logbeta_g[1] + s_logbeta_g[2];
     const double* sc = buf.data() + c->lay.scal();
-    const double L = (double)c->Lg, M = (double)c->M, H = (double)c->H, MH = M * H;
+    // MH: params.MH, the length of the (trimmed) ATVecHat (:483); every other size below is the model's own
+    const double L = (double)c->Lg, M = (double)c->M, H = (double)c->H, MH = trimmed ? n_keep : M * H;
     const double LN2PI = std::log(2.0 * M_PI);
     const double sig = sc[S_SIGMA2], zeta = sc[S_ZETA], trYY = sc[S_TRYY], trBQ = sc[S_TRYBA];
     auto at = [&](long long off, int i, int j) { return buf[(size_t)off + (size_t)i * c->Hp + j]; };
@@ -2299,6 +2360,15 @@ int vbmf_sparse_lower_bound(vbmf_ctx* c, int clamp, double* lb) {
     Lb += H * (c->gamma_ + std::lgamma(c->gamma_) + (1 - c->gamma_) * digamma_host(c->gamma_)) + sumlogdelta; // :469
     *lb = Lb;
     return VBMF_OK;
+}
+
+extern "C" {
+
+int vbmf_sparse_lower_bound(vbmf_ctx* c, int clamp, double* lb) { return sparse_lower_bound_impl(c, clamp, -1.0, lb); }
+
+int vbmf_sparse_lower_bound_trimmed(vbmf_ctx* c, int clamp, double trim, double* lb) {
+    if (c && !(trim >= 0.0)) FAIL(c, VBMF_ERR_INVALID, "vbmf_sparse_lower_bound_trimmed: trim must be >= 0");
+    return sparse_lower_bound_impl(c, clamp, trim, lb);
 }
 
 }  // extern "C"

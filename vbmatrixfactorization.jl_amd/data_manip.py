@@ -4,16 +4,19 @@ load_log, extract_params!), SURVEY.md section 8f row N2.
 Same structure as the reference's log: a dictionary with one entry per field of the parameter type, scalars
 collected into vectors, arrays concatenated along a NEW TRAILING axis (time is always the last dimension,
 src/data_manip.jl:41,97-99); slice 0 is the state before the first sweep (src/vbmf.jl:181-184).
-On disk the reference writes JLD (HDF5) through the JLD package; there is no HDF5 library in this image, so the
-container here is NumPy's .npz with the same names and shapes:  <logdir>/<desc>/log.npz and inputs.npz
-(src/data_manip.jl:62-68).  Fields that are None (YHat beyond the materialisation limit, the dense MH x MH
-covariances of the full_cov branch) are not logged.  Indices are 0-based (the reference's t is 1-based)."""
+On disk it is the reference's own container: JLD (HDF5) files  <logdir>/<desc>/log.jld  and  inputs.jld
+(src/data_manip.jl:62-68), written and read by jld.py through the image's libhdf5 with the layout of the files the
+reference itself recorded -- so `load_log` opens the reference's examples/data/*/ directories directly and the
+reference's tooling sees its own format.  Fields that are None (YHat beyond the materialisation limit, the dense
+MH x MH covariances of the full_cov branch) are not logged.  Indices are 0-based (the reference's t is 1-based)."""
 import dataclasses
 import datetime
 import json
 import os
 
 import numpy as np
+
+from . import jld
 
 
 def _named_values(params):
@@ -52,19 +55,27 @@ def update_log_(logVar, params):
 
 
 def save_log(logVar, Y, priors, logdir, desc=""):
-    """save_log -- src/data_manip.jl:53-69.  Returns the directory written."""
+    """save_log -- src/data_manip.jl:53-69: <logdir>/<desc>/log.jld and inputs.jld (JLD = HDF5 with Julia's conventions:
+    dims reversed, column-major bytes; see jld.py).  `priors` is the reference's `Dict()` (src/vbmf.jl:177): always empty.
+    Returns the directory written."""
     if desc == "":
         desc = datetime.datetime.now().strftime("%Y%m%d_%H%M%S")
     d = os.path.join(logdir, desc)
     os.makedirs(d, exist_ok=True)
-    np.savez(os.path.join(d, "log.npz"), **logVar)
-    np.savez(os.path.join(d, "inputs.npz"), Y=np.asarray(Y), priors=np.array(json.dumps(priors or {})))
+    jld.save(os.path.join(d, "log.jld"), logVar)
+    jld.save(os.path.join(d, "inputs.jld"), {"Y": np.asarray(Y, dtype=np.float64), "priors": dict(priors or {})})
     return d
 
 
 def load_log(path):
-    """load_log -- src/data_manip.jl:77-93: (logVar, Y, priors)."""
+    """load_log -- src/data_manip.jl:77-93: (logVar, Y, priors) from <path>/log.jld and <path>/inputs.jld -- e.g. the
+    reference's own examples/data/vbmf_test.  (A directory written by round 1 of this build, log.npz / inputs.npz, is
+    still readable.)"""
     try:
+        if os.path.exists(os.path.join(path, "log.jld")):
+            logVar = jld.load(os.path.join(path, "log.jld"))
+            inputs = jld.load(os.path.join(path, "inputs.jld"))
+            return logVar, inputs["Y"], inputs["priors"]
         with np.load(os.path.join(path, "log.npz")) as z:
             logVar = {k: z[k] for k in z.files}
         with np.load(os.path.join(path, "inputs.npz")) as z:

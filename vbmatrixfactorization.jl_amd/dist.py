@@ -4,7 +4,8 @@ Y is partitioned by rows: rank g owns Y_g (L_g x M) and BHat_g (L_g x H) permane
 SigmaB, CA, CB, sigma2 are replicated.  Per sweep the library issues exactly two collectives on its
 compute stream (RCCL all-reduce, sum):
     1. the M x H partial  P_g = Y_g' BHat_g            (fp32, after the split-K slab sum)
-    2. the packed Grams   [B_g'B_g | dB_g'dB_g]        (fp64, 2*Hp^2)
+    2. the packed sums    [B_g'B_g | dB_g'dB_g | sum (Y_g A) o B_g]   (fp64, 2*Hp^2 + 1; the last is this rank's part of
+       tr(Y'BA') of updateSigma2!, src/vbmf.jl:154)
 plus one all-reduce of ||Y_g||^2 at set-up.  L x H data never moves.
 """
 
