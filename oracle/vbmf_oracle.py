@@ -525,6 +525,26 @@ def lowerBound(Y, p, clamp=True):
     return float(Lb)
 
 
+def lowerBoundTrimmed(Y, p_in, trim=1e-1, clamp=True):
+    """src/vbmf_sparse.jl:478-489 (the grouped models' copies: src/vbmf_dual.jl:606-617, src/vbmf_trial.jl:687-698): the
+    entries of vec(A') with abs(ATVecHat) <= trim leave ATVecHat, beta, CA, diagSigmaATVec and MH; AHat (hence Y*AHat,
+    AHat'AHat) and every per-group field (beta0, CA0, ...) stay whole -- exactly the fields the reference reassigns --
+    then lowerBound of the type."""
+    import copy as _copy
+    p = _copy.copy(p_in)
+    keep = np.abs(p.ATVecHat) > trim                                # :481
+    p.ATVecHat = p.ATVecHat[keep]
+    p.MH = int(p.ATVecHat.shape[0])
+    p.beta = p.beta[keep]
+    p.CA = p.CA[keep]
+    p.diagSigmaATVec = p.diagSigmaATVec[keep]
+    if isinstance(p, vbmf_trial_parameters):
+        return lowerBound_trial(Y, p, clamp=clamp)
+    if isinstance(p, vbmf_dual_parameters):
+        return lowerBound_dual(Y, p, clamp=clamp)
+    return lowerBound(Y, p, clamp=clamp)
+
+
 # ----------------------------------------------------------------------------------------------
 # Two-group ARD variant  (src/vbmf_dual.jl), diagonal branch (full_cov=false)
 #

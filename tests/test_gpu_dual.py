@@ -244,3 +244,21 @@ def test_dual_full_cov_as_the_mil_callers_run_it(pkg):
     d_ref, n = O.vbmf_dual_(Yf, po, 10, eps=0.0, full_cov=True, est_priors=True)
     _cmp("full_cov run10 f32", pg, po, 2e-3, priors_tol=2e-3)
     assert np.any(pg.SigmaA != np.diag(np.diag(pg.SigmaA))) and abs(d_gpu - d_ref) <= 2e-2 * d_ref + 2e-6
+
+
+def test_dual_lower_bound_trimmed(pkg):
+    """lowerBoundTrimmed of the two-group model (src/vbmf_dual.jl:606-617): only the vec fields are trimmed there, the
+    per-group fields stay whole -- so MH, the CA-weighted second moment and H(vec(A')) change, the group terms do not."""
+    L, M, H, H0 = 300, 170, 5, 3
+    Y, po = _mk(L, M, H, H0, 71)
+    pkg.set_defaults(y_dtype=pkg.VBMF_Y_F32, factor_dtype=pkg.VBMF_FACTOR_AUTO)
+    Yf = Y.astype(np.float32).astype(np.float64)
+    po.trYTY = float(np.sum(Yf * Yf))
+    O.vbmf_dual_(Yf, po, 8, eps=0.0, est_cb=True, est_priors=True)
+    po.ATVecHat = po.ATVecHat.astype(np.float32).astype(np.float64)
+    po.AHat = po.ATVecHat.reshape(M, H).copy()
+    po.A0Hat, po.A1Hat = po.AHat[:, :H0].copy(), po.AHat[:, H0:].copy()
+    for trim in (1e-1, 0.7):
+        want, got = O.lowerBoundTrimmed(Yf, po, trim), pkg.lowerBoundTrimmed(Yf, _to_pkg(pkg, po), trim)
+        report(f"dual lowerBoundTrimmed trim={trim:g}: gpu {got:.6f} oracle {want:.6f} (untrimmed {O.lowerBound_dual(Yf, po):.6f})")
+        assert abs(got - want) <= 1e-5 * abs(want) + 1e-3, (trim, got, want)

@@ -420,3 +420,38 @@ def test_stream_geometry_forced(pkg, monkeypatch, geometry, mode, L, M, H):
     _, n, d = O.vbmf_(Ys, po, 3, eps=0.0, est_covs=True, est_var=True)
     compare(f"{geometry} geometry {mode} {L}x{M} H{H} run3", pg, po, {k: 6 * v for k, v in tol.items()})
     assert pg._last_run[0] == 3 and abs(pg._last_run[1] - d) <= 5e-3 * d + D_ATOL
+
+
+# ---- the reference-style API's device cache --------------------------------------------------------------------------------
+def test_cached_session_sees_in_place_changes_of_Y(pkg):
+    """The reference reads the caller's Y on every call; here it is uploaded once per array object.  Changing the SAME array
+    in place (Y *= lam; Y[:] = other) must not leave the device on the stale copy: every cache hit re-checks a content
+    fingerprint and uploads again when it differs."""
+    L, M, H = 300, 180, 5
+    Y, po = _problem(L, M, H, 777)
+    pkg.set_defaults(y_dtype=pkg.VBMF_Y_F32, factor_dtype=pkg.VBMF_FACTOR_AUTO)
+    Yw = Y.astype(np.float32).astype(np.float64)                      # ONE array object, edited in place below
+    for step, edit in enumerate((lambda: None, lambda: Yw.__imul__(1.5), lambda: Yw.__setitem__(slice(None), Yw[::-1].copy()))):
+        edit()
+        Yf = Yw.astype(np.float32).astype(np.float64)
+        pg, pr = to_pkg_params(pkg, po), clone_oracle(po)
+        pkg.updateA_(Yw, pg); O.updateA(Yf, pr)
+        compare(f"cache step {step} updateA", pg, pr, TOL_F32, fields=("AHat", "SigmaA"))
+        pg = to_pkg_params(pkg, po)
+        pkg.updateSigma2_(Yw, pg); O.updateSigma2(Yf, pr := clone_oracle(po))
+        compare(f"cache step {step} updateSigma2", pg, pr, TOL_F32, fields=())
+
+
+def test_updates_without_Y(pkg):
+    """updateCA! / updateCB! / updateYHat! take no Y in the reference (src/vbmf.jl:120-146): same here."""
+    L, M, H = 200, 100, 5
+    Y, po = _problem(L, M, H, 778)
+    pkg.set_defaults(y_dtype=pkg.VBMF_Y_F32, factor_dtype=pkg.VBMF_FACTOR_AUTO)
+    Yf = Y.astype(np.float32).astype(np.float64)
+    O.updateA(Yf, po); O.updateB(Yf, po)
+    pkg.invalidate()
+    pg = to_pkg_params(pkg, po)
+    pkg.updateCA_(pg); pkg.updateCB_(pg); pkg.updateYHat_(pg)
+    O.updateCA(po); O.updateCB(po)
+    compare("Y-free updateC", pg, po, TOL_F32, fields=("CA", "CB", "invCA", "invCB"))
+    assert relF(pg.YHat, po.BHat @ po.AHat.T) < 1e-6

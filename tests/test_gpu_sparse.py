@@ -317,3 +317,69 @@ def test_full_cov_against_the_oracle(pkg, L, M, H):
         assert abs(lb_gpu - lb_ref) <= 2e-5 * abs(lb_ref)
     with pytest.raises(NotImplementedError):
         pkg.sparse_updateA_(Yf, pg, full_cov=True, diag_var=True)
+
+
+def test_lower_bound_trimmed(pkg):
+    """lowerBoundTrimmed (src/vbmf_sparse.jl:478-489; examples/mil_util.jl:505): the device masks its M*H-long sums with
+    |ATVecHat| > trim; the oracle trims the vectors like the reference and calls lowerBound.  PARITY UNPINNED (no recorded value)."""
+    L, M, H = 400, 260, 6
+    Y, po = _mk(L, M, H, 31)
+    pkg.set_defaults(y_dtype=pkg.VBMF_Y_F32, factor_dtype=pkg.VBMF_FACTOR_AUTO)
+    Yf = Y.astype(np.float32).astype(np.float64)
+    po.trYTY = float(np.sum(Yf * Yf))
+    O.vbmf_sparse_(Yf, po, 10, eps=0.0, full_cov=False, est_cb=True)
+    po.ATVecHat = po.ATVecHat.astype(np.float32).astype(np.float64)      # the device compares its fp32 copy with trim
+    po.AHat = po.ATVecHat.reshape(M, H).copy()
+    full = O.lowerBound(Yf, po)
+    seen = set()
+    for trim in (0.0, 1e-1, 0.5, 1e9):
+        want = O.lowerBoundTrimmed(Yf, po, trim)
+        got = pkg.lowerBoundTrimmed(Yf, _to_pkg(pkg, po), trim)
+        kept = int(np.sum(np.abs(po.ATVecHat) > trim))
+        report(f"sparse lowerBoundTrimmed trim={trim:g}: kept {kept} of {M * H}; gpu {got:.6f} oracle {want:.6f} (untrimmed {full:.6f})")
+        assert abs(got - want) <= 1e-5 * abs(want) + 1e-3, (trim, got, want)
+        seen.add(kept)
+    assert len(seen) >= 3 and 0 in seen                     # the masks really differed, down to the empty one
+    with pytest.raises(pkg.VbmfError):
+        pkg.lowerBoundTrimmed(Yf, _to_pkg(pkg, po), -1.0)
+
+
+def test_first_update_on_a_fresh_init_is_updateB(pkg):
+    """A fresh vbmf_sparse_init state holds SigmaA = zeros beside diagSigmaATVec = ones (src/vbmf_sparse.jl:120-123); calling
+    updateB! / updateSigma! / lowerBound BEFORE any updateA! must use that zero SigmaA, not the column sums of diagSigmaATVec."""
+    L, M, H = 300, 170, 5
+    Y, po = _mk(L, M, H, 52)
+    pkg.set_defaults(y_dtype=pkg.VBMF_Y_F32, factor_dtype=pkg.VBMF_FACTOR_AUTO)
+    Yf = Y.astype(np.float32).astype(np.float64)
+    po.trYTY = float(np.sum(Yf * Yf))
+    assert not po.SigmaA.any() and np.all(po.diagSigmaATVec == 1.0)
+    pg = _to_pkg(pkg, po)
+    pkg.sparse_updateB_(Yf, pg); O.sparse_updateB(Yf, po)
+    _cmp("fresh-init updateB", pg, po, 5e-5, ("BHat", "SigmaB"))
+    pg = _to_pkg(pkg, po)
+    pkg.sparse_updateSigma_(Yf, pg); O.sparse_updateSigma(Yf, po)
+    _cmp("fresh-init updateSigma", pg, po, 5e-4, ())
+    lb, lbo = pkg.lowerBound(Yf, _to_pkg(pkg, po)), O.lowerBound(Yf, po)
+    assert abs(lb - lbo) <= 1e-5 * abs(lbo) + 1e-3, (lb, lbo)
+
+
+def test_updates_without_Y_and_derived_constants(pkg):
+    """updateCA! / updateCB! take no Y in the reference (src/vbmf_sparse.jl:284-300): the same calls work here, with or without
+    a cached device copy of a matrix; a struct whose derived constants (alpha, gamma, eta) disagree with its hyper-priors is refused."""
+    L, M, H = 200, 120, 4
+    Y, po = _mk(L, M, H, 63)
+    pkg.set_defaults(y_dtype=pkg.VBMF_Y_F32, factor_dtype=pkg.VBMF_FACTOR_AUTO)
+    Yf = Y.astype(np.float32).astype(np.float64)
+    O.sparse_updateA(Yf, po, full_cov=False); O.sparse_updateB(Yf, po)
+    pkg.invalidate()                                        # no cached context: the Y-free path creates one without a matrix
+    pa, pb = _to_pkg(pkg, po), _to_pkg(pkg, po)
+    pkg.sparse_updateCA_(pa); pkg.sparse_updateCB_(pa)
+    pkg.sparse_updateCA_(pb, Y=Yf); pkg.sparse_updateCB_(pb, Y=Yf)
+    O.sparse_updateCA(po); O.sparse_updateCB(po)
+    for f in ("CA", "beta", "CB", "delta"):
+        assert np.array_equal(getattr(pa, f), getattr(pb, f)), f
+    _cmp("Y-free updateC", pa, po, 5e-5, ("CA", "beta", "CB", "delta"))
+    bad = _to_pkg(pkg, po)
+    bad.gamma = bad.gamma + 1.0
+    with pytest.raises(ValueError, match="derived"):
+        pkg.sparse_updateCB_(bad)

@@ -237,3 +237,20 @@ def test_trial_odd_shapes_all_branches(pkg, L, M, H, H0, M0):
         pg = _to_pkg(pkg, qo)
         pkg.trial_updateB_(Yf, pg); O.sparse_updateB(Yf, qo)
         _cmp(f"{tag} updateB after full_cov={full}", pg, qo, 5e-5, ("BHat", "SigmaB"))
+
+
+def test_trial_lower_bound_trimmed(pkg):
+    """lowerBoundTrimmed of the three-group model (src/vbmf_trial.jl:687-698), as test_dual_lower_bound_trimmed."""
+    L, M, H, H0, M0 = 300, 170, 5, 3, 60
+    Y, po = _mk(L, M, H, H0, M0, 81)
+    pkg.set_defaults(y_dtype=pkg.VBMF_Y_F32, factor_dtype=pkg.VBMF_FACTOR_AUTO)
+    Yf = Y.astype(np.float32).astype(np.float64)
+    po.trYTY = float(np.sum(Yf * Yf))
+    O.vbmf_trial_(Yf, po, 8, eps=0.0, est_cb=True, est_priors=True)
+    po.ATVecHat = po.ATVecHat.astype(np.float32).astype(np.float64)
+    po.AHat = po.ATVecHat.reshape(M, H).copy()
+    po.A1Hat, po.A2Hat, po.A3Hat = po.AHat[:, :H0].copy(), po.AHat[:M0, H0:].copy(), po.AHat[M0:, H0:].copy()
+    for trim in (1e-1, 0.7):
+        want, got = O.lowerBoundTrimmed(Yf, po, trim), pkg.lowerBoundTrimmed(Yf, _to_pkg(pkg, po), trim)
+        report(f"trial lowerBoundTrimmed trim={trim:g}: gpu {got:.6f} oracle {want:.6f}")
+        assert abs(got - want) <= 1e-5 * abs(want) + 1e-3, (trim, got, want)

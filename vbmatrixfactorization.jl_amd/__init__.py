@@ -39,7 +39,7 @@ from .capi import (Context, VbmfError, VBMF_Y_F32, VBMF_Y_BF16, VBMF_FACTOR_AUTO
 
 __all__ = ["vbmf_parameters", "vbmf_init", "vbmf", "vbmf_", "copy", "updateA_", "updateB_", "updateCA_",
            "updateCB_", "updateSigma2_", "updateYHat_", "elbo", "Session", "set_defaults", "capi",
-           "vbmf_sparse_parameters", "vbmf_sparse_init", "vbmf_sparse", "vbmf_sparse_", "lowerBound",
+           "vbmf_sparse_parameters", "vbmf_sparse_init", "vbmf_sparse", "vbmf_sparse_", "lowerBound", "lowerBoundTrimmed", "invalidate",
            "sparse_updateA_", "sparse_updateB_", "sparse_updateCA_", "sparse_updateCB_", "sparse_updateSigma_",
            "vbmf_dual_parameters", "vbmf_dual_init", "vbmf_dual", "vbmf_dual_", "lowerBound_dual", "dual_updateA_",
            "dual_updateB_", "dual_updateCA_", "dual_updateCB_", "dual_updateSigma_", "dual_updateCA_and_priors_",
@@ -50,11 +50,16 @@ __all__ = ["vbmf_parameters", "vbmf_init", "vbmf", "vbmf_", "copy", "updateA_", 
 # elements the field is left None and computed on demand with updateYHat_ (8 GB at 100k x 10k).
 YHAT_AUTO_LIMIT = 1 << 24
 
-_defaults = dict(y_dtype=VBMF_Y_BF16, factor_dtype=VBMF_FACTOR_AUTO, device=0)
+# The reference-style functions take the caller's Array{Float64} Y; by default it is stored on the device in fp32 (exact-f32
+# MFMA, 2^-24 per entry).  bf16 storage (2^-9 per entry of Y: the BASELINE headline configuration, what bench.py passes
+# explicitly) is an opt-in through set_defaults(y_dtype=VBMF_Y_BF16): it changes the data the model sees, which a drop-in
+# caller must choose knowingly -- sigma2 is a cancellation of ||Y||^2 against the reconstruction.
+_defaults = dict(y_dtype=VBMF_Y_F32, factor_dtype=VBMF_FACTOR_AUTO, device=0)
 
 
 def set_defaults(**kw):
-    """Device storage of Y / MFMA operand precision used by the reference-style functions."""
+    """Device storage of Y / MFMA operand precision used by the reference-style functions (y_dtype: VBMF_Y_F32 (default) or
+    VBMF_Y_BF16; factor_dtype: VBMF_FACTOR_AUTO / _BF16 / _BF16X2 with bf16 Y)."""
     for k in kw:
         if k not in _defaults:
             raise KeyError(k)
@@ -175,7 +180,30 @@ class Session:
 
 
 # ---- cached sessions keyed on the caller's Y array ------------------------------------------------
+# The reference reads the caller's Y on every call; here the matrix is uploaded once and kept on the device, so a cache hit
+# must notice when the SAME array object has been changed in place (Y *= lam, Y[:] = other, preprocess into the same buffer).
+# Every hit therefore re-checks a content fingerprint: the whole array up to _FP_FULL elements, beyond that an evenly strided
+# sample of _FP_SAMPLE elements (sum, sum of |.|, CRC32 of the bytes).  A change that touches only entries between the
+# sample points of a huge array is the one case it cannot see: call invalidate(Y) after such an edit.
 _sessions = {}
+_FP_FULL, _FP_SAMPLE = 1 << 22, 1 << 16
+
+
+def _fingerprint(Y):
+    import zlib
+    flat = Y.ravel(order="K")                  # a view for C- or F-contiguous arrays
+    if flat.size > _FP_FULL:
+        flat = flat[::max(1, flat.size // _FP_SAMPLE)]
+    flat = np.ascontiguousarray(flat)
+    return (float(flat.sum()), float(np.abs(flat).sum()), zlib.crc32(flat.tobytes()))
+
+
+def invalidate(Y=None):
+    """Drop the device copies cached for `Y` (all of them when Y is None): the next call uploads the matrix again."""
+    for cache in (_sessions, _sparse_sessions):
+        for k in [k for k, v in cache.items() if Y is None or v[1]() is Y or v[1]() is None]:
+            ent = cache.pop(k)
+            ent[0].close()
 
 
 def _session_for(Y, H):
@@ -184,7 +212,11 @@ def _session_for(Y, H):
         raise ValueError("Y must be a matrix")
     key = (id(Y), Y.shape, Y.__array_interface__["data"][0], int(H), tuple(sorted(_defaults.items())))
     ent = _sessions.get(key)
+    fp = _fingerprint(Y)
     if ent is not None and ent[1]() is Y:
+        if ent[2] != fp:                       # same array object, new contents: upload again
+            ent[0].set_Y(Y)
+            _sessions[key] = (ent[0], ent[1], fp)
         return ent[0]
     for k in [k for k, v in _sessions.items() if v[1]() is None or k[:3] == key[:3]]:
         _sessions.pop(k)[0].close()
@@ -194,7 +226,22 @@ def _session_for(Y, H):
         ref = weakref.ref(Y)
     except TypeError:
         ref = (lambda y: (lambda: y))(Y)
-    _sessions[key] = (s, ref)
+    _sessions[key] = (s, ref, fp)
+    return s
+
+
+def _session_for_params(p):
+    """Device session for the updates whose reference signatures take NO Y (updateCA!, updateCB!, updateYHat!,
+    src/vbmf.jl:120-146): any cached session of the same problem size serves (state is pushed on every call); without one,
+    a context that is never given a matrix (the library runs these updates from the factors and covariances alone)."""
+    for k, v in _sessions.items():
+        if k[1] == (p.L, p.M) and k[3] == int(p.H) and k[4] == tuple(sorted(_defaults.items())):
+            return v[0]
+    key = ("noY", (p.L, p.M), 0, int(p.H), tuple(sorted(_defaults.items())))
+    for k in [k for k in _sessions if k[0] == "noY"]:
+        _sessions.pop(k)[0].close()
+    s = Session(p.L, p.M, p.H)
+    _sessions[key] = (s, lambda: None, None)
     return s
 
 
@@ -222,17 +269,24 @@ def updateB_(Y, params):
     _one(Y, params, STEP_B, True)
 
 
+def _one_noY(params, which):
+    s = _session_for_params(params)
+    s.push(params)
+    s.step(which)
+    s.pull(params, want_B=False)
+
+
 def updateCA_(params, Y=None):
-    """updateCA! -- src/vbmf.jl:129-134.  (Y only selects the cached device problem.)"""
+    """updateCA! -- src/vbmf.jl:129-134: the reference's signature, no Y (a Y, if given, only selects its cached session)."""
     if Y is None:
-        raise ValueError("updateCA_ needs the Y whose device session holds the problem")
+        return _one_noY(params, STEP_CA)
     _one(Y, params, STEP_CA, False)
 
 
 def updateCB_(params, Y=None):
-    """updateCB! -- src/vbmf.jl:141-146."""
+    """updateCB! -- src/vbmf.jl:141-146: the reference's signature, no Y."""
     if Y is None:
-        raise ValueError("updateCB_ needs the Y whose device session holds the problem")
+        return _one_noY(params, STEP_CB)
     _one(Y, params, STEP_CB, False)
 
 
@@ -242,10 +296,8 @@ def updateSigma2_(Y, params):
 
 
 def updateYHat_(params, Y=None):
-    """updateYHat! -- src/vbmf.jl:120-122 (device GEMM, fp64 out)."""
-    if Y is None:
-        raise ValueError("updateYHat_ needs the Y whose device session holds the problem")
-    s = _session_for(Y, params.H)
+    """updateYHat! -- src/vbmf.jl:120-122 (device GEMM, fp64 out): the reference's signature, no Y."""
+    s = _session_for_params(params) if Y is None else _session_for(Y, params.H)
     s.push(params)
     params.YHat = s.ctx.YHat()
 
@@ -379,11 +431,26 @@ _sparse_sessions = {}
 
 
 def _sparse_ctx(Y, p, diag_var=False, dual=False, trial=False):
-    Y = np.asarray(Y, dtype=np.float64)
-    key = (id(Y), Y.shape, Y.__array_interface__["data"][0], int(p.H), bool(diag_var), bool(dual), bool(trial), tuple(sorted(_defaults.items())))
-    ent = _sparse_sessions.get(key)
-    if ent is not None and ent[1]() is Y:
-        return ent[0]
+    """Y = None: the updates whose reference signatures take no Y (updateCA!, updateCB!: src/vbmf_sparse.jl:284-300 and the
+    grouped models' twins) -- a cached context of the same problem serves, else one that is never given a matrix."""
+    if Y is None:
+        want = (int(p.H), bool(diag_var), bool(dual), bool(trial), tuple(sorted(_defaults.items())))
+        for k, v in _sparse_sessions.items():
+            if k[1] == (p.L, p.M) and k[3:] == want:
+                return v[0]
+        key = ("noY", (p.L, p.M), 0) + want
+    else:
+        Y = np.asarray(Y, dtype=np.float64)
+        if Y.ndim != 2:
+            raise ValueError("Y must be a matrix")
+        key = (id(Y), Y.shape, Y.__array_interface__["data"][0], int(p.H), bool(diag_var), bool(dual), bool(trial), tuple(sorted(_defaults.items())))
+        fp = _fingerprint(Y)
+        ent = _sparse_sessions.get(key)
+        if ent is not None and ent[1]() is Y:
+            if ent[2] != fp:                   # same array object, new contents (see _session_for)
+                ent[0].set_Y(Y)
+                _sparse_sessions[key] = (ent[0], ent[1], fp)
+            return ent[0]
     for k in list(_sparse_sessions):
         _sparse_sessions.pop(k)[0].close()
     if trial:
@@ -392,22 +459,40 @@ def _sparse_ctx(Y, p, diag_var=False, dual=False, trial=False):
         variant = VBMF_VARIANT_DUAL_DIAGVAR if diag_var else VBMF_VARIANT_DUAL_DIAG
     else:
         variant = VBMF_VARIANT_SPARSE_DIAGVAR if diag_var else VBMF_VARIANT_SPARSE_DIAG
+    if Y is None:
+        c = Context(p.L, p.M, p.H, variant=variant, **_defaults)
+        _sparse_sessions[key] = (c, lambda: None, None)
+        return c
     c = Context(Y.shape[0], Y.shape[1], p.H, variant=variant, **_defaults)
     c.set_Y(Y)
-    _sparse_sessions[key] = (c, weakref.ref(Y))
+    _sparse_sessions[key] = (c, weakref.ref(Y), fp)
     return c
 
 
 def _push_SigmaA(c, p, full_cov):
-    """full_cov on/off for the calls that follow; a non-diagonal SigmaA (a full_cov state) is handed over as it is
-    (vbmf_sparse_set_state derives a diagonal one from diagSigmaATVec)."""
+    """full_cov on/off for the calls that follow, and the caller's SigmaA as it is: vbmf_sparse_set_state derives a diagonal
+    one from diagSigmaATVec, which is NOT what a fresh vbmf_sparse_init state holds (SigmaA = zeros beside
+    diagSigmaATVec = ones, src/vbmf_sparse.jl:120-123) nor what a full_cov state holds."""
     c.sparse_set_full_cov(full_cov)
-    S = None if p.SigmaA is None else np.asarray(p.SigmaA)
-    if S is not None and (full_cov or np.any(S != np.diag(np.diag(S)))):
-        c.sparse_set_SigmaA(S)
+    if p.SigmaA is not None:
+        c.sparse_set_SigmaA(np.asarray(p.SigmaA, dtype=np.float64))
+
+
+def _check_derived(p):
+    """alpha, gamma, eta are DERIVED constants in the reference (alpha0 + 1/2, gamma0 + L/2, eta0 + L*M/2, src/vbmf_sparse.jl:
+    131,137,143) and the device derives them the same way from the hyper-priors; a struct that carries other values would be
+    silently overruled, so it is refused instead."""
+    for name, want in (("gamma", p.gamma0 + p.L / 2), ("eta", p.eta0 + p.L * p.M / 2)):
+        have = getattr(p, name, None)
+        if have is not None and np.isscalar(have) and have != 0.0 and abs(have - want) > 1e-9 * max(1.0, abs(want)):
+            raise ValueError(f"params.{name} = {have} is not the derived value {want} the updates use "
+                             f"(src/vbmf_sparse.jl:131-143): set the hyper-prior instead")
 
 
 def _spush(c, p, diag_var=False, full_cov=False):
+    _check_derived(p)
+    if np.isscalar(p.alpha) and p.alpha != 0.0 and abs(p.alpha - (p.alpha0 + 0.5)) > 1e-12:
+        raise ValueError(f"params.alpha = {p.alpha} is not alpha0 + 1/2 (src/vbmf_sparse.jl:131): set alpha0 instead")
     hyper = dict(alpha0=p.alpha0, beta0=p.beta0, gamma0=p.gamma0, delta0=p.delta0, eta0=p.eta0, zeta0=p.zeta0)
     c.sparse_set_state(p.ATVecHat, p.diagSigmaATVec, p.CA, p.beta, p.BHat, p.SigmaB, p.CB, p.delta, p.sigmaHat,
                        p.zeta, hyper, labels0=_labels0(p), H1=p.H1)
@@ -513,6 +598,21 @@ def lowerBound(Y, params, clamp=True):
     return c.sparse_lower_bound(clamp=clamp)
 
 
+def lowerBoundTrimmed(Y, params, trim=1e-1, clamp=True):
+    """lowerBoundTrimmed -- src/vbmf_sparse.jl:478-489 (dual: src/vbmf_dual.jl:606-617, trial: src/vbmf_trial.jl:687-698): the
+    bound without the entries of vec(A') with |ATVecHat| <= trim (the mask sits in front of the device's M*H-long sums)."""
+    if isinstance(params, vbmf_trial_parameters):
+        c = _sparse_ctx(Y, params, trial=True)
+        _tpush(c, params)
+    elif isinstance(params, vbmf_dual_parameters):
+        c = _sparse_ctx(Y, params, dual=True)
+        _dpush(c, params)
+    else:
+        c = _sparse_ctx(Y, params)
+        _spush(c, params)
+    return c.sparse_lower_bound_trimmed(trim, clamp=clamp)
+
+
 # =================================================================================================
 # Two-group ARD variant -- src/vbmf_dual.jl with full_cov=false (either noise model)
 # =================================================================================================
@@ -613,6 +713,7 @@ def vbmf_dual_init(Y, H, H0, ca=1.0, alpha0=1e-10, beta0=1e-10, cb=1.0, gamma0=1
 
 
 def _dpush(c, p, diag_var=False, full_cov=False):
+    _check_derived(p)
     hyper = dict(alpha0=p.alpha00, beta0=p.beta00, gamma0=p.gamma0, delta0=p.delta0, eta0=p.eta0, zeta0=p.zeta0)
     c.sparse_set_state(p.ATVecHat, p.diagSigmaATVec, p.CA, p.beta, p.BHat, p.SigmaB, p.CB, p.delta, p.sigmaHat, p.zeta, hyper)
     c.dual_set_priors(p.H0, p.alpha00, p.beta00, p.alpha01, p.beta01, p.alpha0, p.alpha1)
@@ -846,6 +947,7 @@ def vbmf_trial_init(Y, H, H0, M0, ca=1.0, alpha0=1e-10, beta0=1e-10, cb=1.0, gam
 
 
 def _tpush(c, p, diag_var=False, full_cov=False):
+    _check_derived(p)
     hyper = dict(alpha0=p.alpha01, beta0=p.beta01, gamma0=p.gamma0, delta0=p.delta0, eta0=p.eta0, zeta0=p.zeta0)
     c.sparse_set_state(p.ATVecHat, p.diagSigmaATVec, p.CA, p.beta, p.BHat, p.SigmaB, p.CB, p.delta, p.sigmaHat, p.zeta, hyper)
     c.trial_set_priors(p.H0, p.M0, {k: getattr(p, k) for k in Context.TRIAL_KEYS})
@@ -1002,14 +1104,32 @@ def vbls_(Y, params, niter, diag_var=False, full_cov=False):
 
 
 def copy_vbmf_params(Y, old_params, rng=None):
-    """copy_vbmf_params -- examples/mil_util.jl:212-236: a fresh parameter set for a NEW Y (other M), keeping what
-    vbls! leaves fixed (BHat, SigmaB, CB, invCB [, gamma, delta]).  Labels and H1 are not carried over (:218)."""
-    if isinstance(old_params, vbmf_sparse_parameters):
-        p = vbmf_sparse_init(Y, old_params.H, alpha0=old_params.alpha0, beta0=old_params.beta0, gamma0=old_params.gamma0,
-                             delta0=old_params.delta0, eta0=old_params.eta0, zeta0=old_params.zeta0, rng=rng)
+    """copy_vbmf_params -- examples/mil_util.jl:212-290: a fresh parameter set for a NEW Y (other M), keeping what
+    vbls! leaves fixed (BHat, SigmaB, CB, invCB [, gamma, delta]) and, for the grouped models, the fitted hyper-priors
+    (the three-group model returns TWO sets: groups (1, 2) and (1, 3) of the trained model, each with M0 = M so that its own
+    third group is empty).  Labels and H1 are not carried over (:218)."""
+    def keep(p):                                                        # :240-245, 255-259, 272-276
         p.BHat, p.SigmaB, p.CB = old_params.BHat.copy(), old_params.SigmaB.copy(), old_params.CB.copy()
         p.gamma, p.delta = old_params.gamma, old_params.delta.copy()
         return p
+    if isinstance(old_params, vbmf_trial_parameters):                   # :262-290: TWO parameter sets, one per special basis
+        M = np.asarray(Y).shape[1]
+        kw = dict(gamma0=old_params.gamma0, delta0=old_params.delta0, eta0=old_params.eta0, zeta0=old_params.zeta0, rng=rng)
+        p0 = keep(vbmf_trial_init(Y, old_params.H, old_params.H0, M, **kw))
+        p0.alpha01, p0.beta01, p0.alpha02, p0.beta02 = old_params.alpha01, old_params.beta01, old_params.alpha02, old_params.beta02
+        p0.alpha03, p0.beta03 = 1e-10, 1e-10
+        p1 = keep(vbmf_trial_init(Y, old_params.H, old_params.H0, M, **kw))
+        p1.alpha01, p1.beta01, p1.alpha02, p1.beta02 = old_params.alpha01, old_params.beta01, old_params.alpha03, old_params.beta03
+        p1.alpha03, p1.beta03 = 1e-10, 1e-10
+        return p0, p1
+    if isinstance(old_params, vbmf_dual_parameters):                    # :248-261
+        p = keep(vbmf_dual_init(Y, old_params.H, old_params.H0, gamma0=old_params.gamma0, delta0=old_params.delta0,
+                                eta0=old_params.eta0, zeta0=old_params.zeta0, rng=rng))
+        p.alpha00, p.beta00, p.alpha01, p.beta01 = old_params.alpha00, old_params.beta00, old_params.alpha01, old_params.beta01
+        return p
+    if isinstance(old_params, vbmf_sparse_parameters):
+        return keep(vbmf_sparse_init(Y, old_params.H, alpha0=old_params.alpha0, beta0=old_params.beta0, gamma0=old_params.gamma0,
+                                     delta0=old_params.delta0, eta0=old_params.eta0, zeta0=old_params.zeta0, rng=rng))
     p = vbmf_init(Y, old_params.H, sigma2=old_params.sigma2, rng=rng)
     p.BHat, p.SigmaB = old_params.BHat.copy(), old_params.SigmaB.copy()
     p.CB, p.invCB = old_params.CB.copy(), old_params.invCB.copy()

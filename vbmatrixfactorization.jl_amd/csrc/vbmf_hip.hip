@@ -609,11 +609,13 @@ static int launch_ctrl_end(vbmf_ctx* c, int flags, double eps, double* trace) {
     return VBMF_OK;
 }
 
-static int ensure_ready(vbmf_ctx* c) {
-    if (!c->haveY) FAIL(c, VBMF_ERR_INVALID, "no Y: call vbmf_set_Y or vbmf_set_Y_synthetic first");
+// need_Y = false: updateCA!/updateCB! read the factors and covariances only (src/vbmf.jl:129-146, src/vbmf_sparse.jl:284-300 --
+// the reference's signatures take no Y), so a context that was never given a matrix can run them
+static int ensure_ready(vbmf_ctx* c, bool need_Y = true) {
+    if (need_Y && !c->haveY) FAIL(c, VBMF_ERR_INVALID, "no Y: call vbmf_set_Y or vbmf_set_Y_synthetic first");
     if (!c->haveState) FAIL(c, VBMF_ERR_INVALID, "no state: call vbmf_set_state first");
     if (c->o.nranks > 1 && !c->comm_ready) FAIL(c, VBMF_ERR_COMM, "nranks > 1 but vbmf_comm_init was not called");
-    if (!c->trYY_reduced) {
+    if (c->haveY && !c->trYY_reduced) {
         double* dst = c->st + c->lay.scal() + S_TRYY;
         HIPCHK(c, hipMemcpyAsync(dst, &c->trYY_local, sizeof(double), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1349,7 +1351,7 @@ int vbmf_step(vbmf_ctx* c, int which) {
     if (c->sparse) FAIL(c, VBMF_ERR_INVALID, "sparse context: use vbmf_sparse_step");
     if (which & ~31) FAIL(c, VBMF_ERR_INVALID, "vbmf_step: unknown update bits");
     HIPCHK(c, hipSetDevice(c->o.device));
-    TRY(ensure_ready(c));
+    TRY(ensure_ready(c, (which & (VBMF_STEP_A | VBMF_STEP_B | VBMF_STEP_SIGMA2)) != 0));
     if (which & VBMF_STEP_A) TRY(do_update_A(c));
     if (which & VBMF_STEP_B) TRY(do_update_B(c));
     int flags = 0;
@@ -1363,7 +1365,7 @@ int vbmf_step(vbmf_ctx* c, int which) {
         flags |= 4 | f;
     }
     if (flags) {
-        if (!(flags & 4)) { TRY(ensure_gram_A(c)); TRY(ensure_gram_B(c)); flags |= c->tr_valid ? 16 : 0; }
+        if (!(flags & 4)) { TRY(ensure_gram_A(c)); TRY(ensure_gram_B(c)); }
         TRY(launch_ctrl_end(c, flags, 0.0, nullptr));
     }
     return check_device_err(c);
@@ -1998,7 +2000,7 @@ int vbmf_sparse_step(vbmf_ctx* c, int which) {
     if ((which & VBMF_SSTEP_PRIORS) && !(which & VBMF_SSTEP_CA))
         FAIL(c, VBMF_ERR_INVALID, "VBMF_SSTEP_PRIORS needs the group sums of VBMF_SSTEP_CA in the same call");
     HIPCHK(c, hipSetDevice(c->o.device));
-    TRY(ensure_ready(c));
+    TRY(ensure_ready(c, (which & (VBMF_SSTEP_A | VBMF_SSTEP_B | VBMF_SSTEP_SIGMA)) != 0));
     if (which & VBMF_SSTEP_A) TRY(do_sparse_update_A(c));
     if (which & VBMF_SSTEP_B) TRY(do_sparse_update_B(c));
     if (which & VBMF_SSTEP_CA) TRY(sparse_update_CA(c));

@@ -11,9 +11,10 @@
 module VBMatrixFactorizationHIP
 
 export vbmf_parameters, vbmf_init, vbmf, vbmf!, updateA!, updateB!, updateCA!, updateCB!, updateSigma2!, updateYHat!,
-       vbls!, copy_vbmf_params, preprocess_device, vbmf_on!,
-       vbmf_sparse_parameters, vbmf_sparse_init, vbmf_sparse!, lowerBound,
-       vbmf_dual_parameters, vbmf_dual_init, vbmf_dual!
+       vbls!, copy_vbmf_params, preprocess_device, vbmf_on!, invalidate!,
+       vbmf_sparse_parameters, vbmf_sparse_init, vbmf_sparse!, lowerBound, lowerBoundTrimmed,
+       vbmf_dual_parameters, vbmf_dual_init, vbmf_dual!,
+       vbmf_trial_parameters, vbmf_trial_init, vbmf_trial!
 
 const libvbmf = get(ENV, "VBMF_HIP_LIB", joinpath(@__DIR__, "..", "libvbmf_hip.so"))
 
@@ -59,6 +60,21 @@ const STEP_A, STEP_B, STEP_CA, STEP_CB, STEP_SIGMA2 = 1, 2, 4, 8, 16
 mutable struct Ctx
     h::Ptr{Cvoid}
     Y::Array{Float64,2}       # keeps the identity of the uploaded Y
+    fp::UInt                  # content fingerprint of Y at upload time (see fingerprint)
+end
+Ctx(h::Ptr{Cvoid}, Y::Array{Float64,2}) = Ctx(h, Y, fingerprint(Y))
+
+# The reference reads the caller's Y on every call; here it is uploaded once per array object, so a cache hit re-checks a
+# content fingerprint (all of Y up to 4M entries, an evenly strided sample of ~64k beyond) and uploads again when the SAME
+# array was changed in place (Y .*= lam, Y[:] = other).  invalidate!(Y) drops the device copy explicitly.
+function fingerprint(Y::Array{Float64,2})
+    n = length(Y)
+    st = n > (1 << 22) ? max(1, n >> 16) : 1
+    h = hash(n)
+    @inbounds for i in 1:st:n
+        h = hash(Y[i], h)
+    end
+    return h
 end
 
 function chk(h::Ptr{Cvoid}, rc::Cint)
@@ -69,18 +85,51 @@ end
 
 const _cache = Dict{UInt,Ctx}()
 
-"One device context per Y array (uploaded once); y_dtype from ENV[\"VBMF_HIP_Y\"] = \"bf16\" | \"f32\"."
+# fp32 storage of the caller's Float64 Y by default; ENV["VBMF_HIP_Y"] = "bf16" opts into bf16 storage (the BASELINE headline
+# configuration): that changes the data the model sees and must be chosen knowingly
+y_dtype() = get(ENV, "VBMF_HIP_Y", "f32") == "bf16" ? VBMF_Y_BF16 : VBMF_Y_F32
+
+function refresh!(c::Ctx, Y::Array{Float64,2})
+    fp = fingerprint(Y)
+    if fp != c.fp                                          # same array object, new contents: upload again
+        chk(c.h, ccall((:vbmf_set_Y, libvbmf), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64), c.h, Y, size(Y, 1)))
+        c.fp = fp
+    end
+    return c
+end
+
+"Drop the cached device copies of Y (all of them without an argument)."
+function invalidate!(Y = nothing)
+    for d in (_cache, _scache), (k, c) in collect(d)
+        (Y === nothing || c.Y === Y) && (finalize(c); delete!(d, k))
+    end
+end
+
+"One device context per Y array (uploaded once, re-uploaded when its contents change)."
 function ctx_for(Y::Array{Float64,2}, H::Int)
     key = hash((objectid(Y), size(Y), H))
-    haskey(_cache, key) && return _cache[key]
+    haskey(_cache, key) && return refresh!(_cache[key], Y)
     L, M = size(Y)
-    ydt = get(ENV, "VBMF_HIP_Y", "bf16") == "f32" ? VBMF_Y_F32 : VBMF_Y_BF16
+    ydt = y_dtype()
     opts = Ref(VbmfOpts(Int32(sizeof(VbmfOpts)), 0, ydt, 0, 0, 0xffffffff, 1, 0, 0, 0, 0, 0))
     h = Ref{Ptr{Cvoid}}(C_NULL)
     rc = ccall((:vbmf_create, libvbmf), Cint, (Ref{Ptr{Cvoid}}, Int64, Int64, Int64, Ref{VbmfOpts}), h, L, M, H, opts)
     chk(Ptr{Cvoid}(C_NULL), rc)
     chk(h[], ccall((:vbmf_set_Y, libvbmf), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64), h[], Y, L))
     c = Ctx(h[], Y)
+    finalizer(x -> ccall((:vbmf_destroy, libvbmf), Cint, (Ptr{Cvoid},), x.h), c)
+    _cache[key] = c
+    return c
+end
+
+"Context for the updates whose reference signatures take no Y (updateCA!, updateCB!, updateYHat!): never given a matrix."
+function ctx_noY(L::Int, M::Int, H::Int; variant::Int = 0)
+    key = hash((:noY, L, M, H, variant))
+    haskey(_cache, key) && return _cache[key]
+    opts = Ref(VbmfOpts(Int32(sizeof(VbmfOpts)), 0, y_dtype(), 0, variant, 0xffffffff, 1, 0, 0, 0, 0, 0))
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    chk(Ptr{Cvoid}(C_NULL), ccall((:vbmf_create, libvbmf), Cint, (Ref{Ptr{Cvoid}}, Int64, Int64, Int64, Ref{VbmfOpts}), h, L, M, H, opts))
+    c = Ctx(h[], Array{Float64}(undef, 0, 0), UInt(0))
     finalizer(x -> ccall((:vbmf_destroy, libvbmf), Cint, (Ptr{Cvoid},), x.h), c)
     _cache[key] = c
     return c
@@ -146,11 +195,16 @@ end
 updateA!(Y::Array{Float64,2}, params::vbmf_parameters) = step!(Y, params, STEP_A)            # src/vbmf.jl:95-102
 updateB!(Y::Array{Float64,2}, params::vbmf_parameters) = step!(Y, params, STEP_B)            # :109-113
 updateSigma2!(Y::Array{Float64,2}, params::vbmf_parameters) = step!(Y, params, STEP_SIGMA2)  # :153-157
-# the reference's updateCA!/updateCB!/updateYHat! take only params; here the Y selects the device context
-updateCA!(params::vbmf_parameters, Y::Array{Float64,2}) = step!(Y, params, STEP_CA)          # :129-134
-updateCB!(params::vbmf_parameters, Y::Array{Float64,2}) = step!(Y, params, STEP_CB)          # :141-146
-function updateYHat!(params::vbmf_parameters, Y::Array{Float64,2})                           # :120-122
-    c = ctx_for(Y, params.H); push!(c, params)
+# the reference's updateCA!/updateCB!/updateYHat! take only params (src/vbmf.jl:120-146): so do these -- the library runs
+# them from the factors and covariances alone, on a context that holds no matrix
+function step_noY!(p::vbmf_parameters, which)
+    c = ctx_noY(p.L, p.M, p.H); push!(c, p)
+    chk(c.h, ccall((:vbmf_step, libvbmf), Cint, (Ptr{Cvoid}, Cint), c.h, which)); pull!(c, p); nothing
+end
+updateCA!(params::vbmf_parameters) = step_noY!(params, STEP_CA)                               # :129-134
+updateCB!(params::vbmf_parameters) = step_noY!(params, STEP_CB)                               # :141-146
+function updateYHat!(params::vbmf_parameters)                                                # :120-122
+    c = ctx_noY(params.L, params.M, params.H); push!(c, params)
     params.YHat = Array{Float64}(undef, params.L, params.M)
     chk(c.h, ccall((:vbmf_get_YHat, libvbmf), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64), c.h, params.YHat, params.L))
 end
@@ -158,7 +212,8 @@ end
 "vbmf! -- src/vbmf.jl:175-231"
 function vbmf!(Y::Array{Float64,2}, params::vbmf_parameters, niter::Int; eps::Float64 = 1e-6, est_covs::Bool = false,
                est_var::Bool = false, logdir = "", desc = "", verb = false)
-    logdir == "" || error("per-iteration JLD logging (src/data_manip.jl) is outside the accelerated path")
+    logdir == "" || error("per-iteration logging: drive the sweeps from the reference's own create_log / update_log! / save_log " *
+                          "(src/data_manip.jl works unchanged on these structs) around vbmf!(Y, params, 1; ...) calls")
     c = ctx_for(Y, params.H)
     push!(c, params)
     iters = Ref{Int64}(0); d = Ref{Float64}(0.0)
@@ -166,7 +221,7 @@ function vbmf!(Y::Array{Float64,2}, params::vbmf_parameters, niter::Int; eps::Fl
         (Ptr{Cvoid}, Int64, Float64, Cint, Cint, Ref{Int64}, Ref{Float64}, Ptr{Float64}),
         c.h, niter, eps, est_covs, est_var, iters, d, C_NULL))
     pull!(c, params)
-    params.L * params.M <= (1 << 24) && updateYHat!(params, Y)                                # :217
+    params.L * params.M <= (1 << 24) && updateYHat!(params)                                   # :217
     verb && print("Factorization finished after ", iters[], " iterations, eps = ", d[], "\n")  # :221
     return params
 end
@@ -186,7 +241,7 @@ function vbls!(Y::Array{Float64,2}, params::vbmf_parameters, niter::Int; diag_va
     push!(c, params)
     chk(c.h, ccall((:vbmf_run_fixed_basis, libvbmf), Cint, (Ptr{Cvoid}, Int64), c.h, niter))
     pull!(c, params)
-    params.L * params.M <= (1 << 24) && updateYHat!(params, Y)                                # :201
+    params.L * params.M <= (1 << 24) && updateYHat!(params)                                   # :201
     return params.AHat
 end
 
@@ -212,7 +267,7 @@ function preprocess_device(Y::Array{Float64,2}, lambda::Float64, H::Int)
     rows = Array{Int64}(undef, nused[])
     ccall((:vbmf_preprocess_rows, libvbmf), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}), plan[], rows, C_NULL, C_NULL)
     h = Ref{Ptr{Cvoid}}(C_NULL)
-    ydt = get(ENV, "VBMF_HIP_Y", "bf16") == "f32" ? VBMF_Y_F32 : VBMF_Y_BF16
+    ydt = y_dtype()
     opts = Ref(VbmfOpts(Int32(sizeof(VbmfOpts)), 0, ydt, 0, 0, 0xffffffff, 1, 0, 0, 0, 0, 0))
     rc = ccall((:vbmf_create, libvbmf), Cint, (Ref{Ptr{Cvoid}}, Int64, Int64, Int64, Ref{VbmfOpts}), h, nused[], M, H, opts)
     rc == 0 || error(unsafe_string(ccall((:vbmf_last_error, libvbmf), Cstring, (Ptr{Cvoid},), C_NULL)))
@@ -275,9 +330,9 @@ end
 const _scache = Dict{UInt,Ctx}()
 function sparse_ctx_for(Y::Array{Float64,2}, H::Int, diag_var::Bool; variant::Int = diag_var ? 2 : 1)
     key = hash((objectid(Y), size(Y), H, variant))
-    haskey(_scache, key) && return _scache[key]
+    haskey(_scache, key) && return refresh!(_scache[key], Y)
     L, M = size(Y)
-    ydt = get(ENV, "VBMF_HIP_Y", "bf16") == "f32" ? VBMF_Y_F32 : VBMF_Y_BF16
+    ydt = y_dtype()
     opts = Ref(VbmfOpts(Int32(sizeof(VbmfOpts)), 0, ydt, 0, variant, 0xffffffff, 1, 0, 0, 0, 0, 0))   # VBMF_VARIANT_*
     h = Ref{Ptr{Cvoid}}(C_NULL)
     chk(Ptr{Cvoid}(C_NULL), ccall((:vbmf_create, libvbmf), Cint, (Ref{Ptr{Cvoid}}, Int64, Int64, Int64, Ref{VbmfOpts}), h, L, M, H, opts))
@@ -302,7 +357,8 @@ end
 # H x H blocks; SigmaA is a full matrix then and is handed over explicitly
 function set_full_cov!(c::Ctx, p, full_cov::Bool)
     chk(c.h, ccall((:vbmf_sparse_set_full_cov, libvbmf), Cint, (Ptr{Cvoid}, Cint), c.h, full_cov))
-    full_cov && chk(c.h, ccall((:vbmf_sparse_set_SigmaA, libvbmf), Cint, (Ptr{Cvoid}, Ptr{Float64}), c.h, p.SigmaA))
+    # always: set_state derives a diagonal SigmaA from diagSigmaATVec, which is not what a fresh init holds (zeros, :120-123)
+    chk(c.h, ccall((:vbmf_sparse_set_SigmaA, libvbmf), Cint, (Ptr{Cvoid}, Ptr{Float64}), c.h, p.SigmaA))
 end
 function pull_SigmaA!(c::Ctx, p)
     S = Array{Float64}(undef, p.H, p.H)
@@ -343,7 +399,7 @@ function vbmf_sparse!(Y::Array{Float64,2}, params::vbmf_sparse_parameters, niter
     chk(c.h, ccall((:vbmf_sparse_run, libvbmf), Cint, (Ptr{Cvoid}, Int64, Float64, Cint, Ref{Int64}, Ref{Float64}, Ptr{Float64}),
                    c.h, niter, eps, est_cb, iters, d, C_NULL))
     spull!(c, params, diag_var)
-    full_cov && pull_SigmaA!(c, params)
+    diag_var || pull_SigmaA!(c, params)
     params.L * params.M <= (1 << 24) && (params.YHat = params.BHat * params.AHat')            # :396
     verb && print("Factorization finished after ", iters[], " iterations, eps = ", d[], "\n")
     return d[]
@@ -351,14 +407,29 @@ end
 
 "lowerBound -- src/vbmf_sparse.jl:435-471 (homoscedastic model)"
 function lowerBound(Y::Array{Float64,2}, params::vbmf_sparse_parameters)
-    c = sparse_ctx_for(Y, params.H, false); spush!(c, params, false)
+    c = sparse_ctx_for(Y, params.H, false); spush!(c, params, false); set_full_cov!(c, params, false)
     lb = Ref{Float64}(0.0)
     chk(c.h, ccall((:vbmf_sparse_lower_bound, libvbmf), Cint, (Ptr{Cvoid}, Cint, Ref{Float64}), c.h, 1, lb))
     return lb[]
 end
 
-# ---- the two-group variant, src/vbmf_dual.jl (the three-group one, src/vbmf_trial.jl, is bound the same way through
-# vbmf_trial_set_priors / vbmf_trial_get_priors / vbmf_trial_run with H0, M0 and nine scalars) --------------------------
+"lowerBoundTrimmed -- src/vbmf_sparse.jl:478-489 (examples/mil_util.jl:505): entries with abs(ATVecHat) <= trim are left out"
+function lowerBoundTrimmed(Y::Array{Float64,2}, params::vbmf_sparse_parameters, trim = 1e-1)
+    c = sparse_ctx_for(Y, params.H, false); spush!(c, params, false); set_full_cov!(c, params, false)
+    lb = Ref{Float64}(0.0)
+    chk(c.h, ccall((:vbmf_sparse_lower_bound_trimmed, libvbmf), Cint, (Ptr{Cvoid}, Cint, Float64, Ref{Float64}), c.h, 1, trim, lb))
+    return lb[]
+end
+
+"updateCA! / updateCB! of the sparse model take no Y (src/vbmf_sparse.jl:284-300)"
+function sparse_step_noY!(p::vbmf_sparse_parameters, which)
+    c = ctx_noY(p.L, p.M, p.H; variant = 1); spush!(c, p, false); set_full_cov!(c, p, false)
+    chk(c.h, ccall((:vbmf_sparse_step, libvbmf), Cint, (Ptr{Cvoid}, Cint), c.h, which)); spull!(c, p, false); nothing
+end
+updateCA!(params::vbmf_sparse_parameters) = sparse_step_noY!(params, 4)      # VBMF_SSTEP_CA
+updateCB!(params::vbmf_sparse_parameters) = sparse_step_noY!(params, 8)      # VBMF_SSTEP_CB
+
+# ---- the two-group variant, src/vbmf_dual.jl ------------------------------------------------------------------------------
 # Field names of the reference's vbmf_dual_parameters (src/vbmf_dual.jl:59-112) minus the dense MH x MH pair.
 mutable struct vbmf_dual_parameters
     L::Int; M::Int; MH::Int; H::Int; H0::Int; H1::Int
@@ -444,6 +515,107 @@ function vbmf_dual!(Y::Array{Float64,2}, p::vbmf_dual_parameters, niter::Int; ep
     p.alpha00, p.beta00, p.alpha01, p.beta01, p.alpha0, p.alpha1 = pr
     p.alpha = [p.alpha0, p.alpha1]
     p.L * p.M <= (1 << 24) && (p.YHat = p.BHat * p.AHat')                                       # :516
+    verb && print("Factorization finished after ", iters[], " iterations, eps = ", d[], "\n")
+    return d[]
+end
+
+# ---- the three-group variant, src/vbmf_trial.jl ---------------------------------------------------------------------------
+# Field names of the reference's vbmf_trial_parameters (src/vbmf_trial.jl:68-131) minus the dense MH x MH pair.
+mutable struct vbmf_trial_parameters
+    L::Int; M::Int; M0::Int; M1::Int; MH::Int; H::Int; H0::Int; H1::Int
+    AHat::Array{Float64,2}; ATVecHat::Array{Float64,1}; diagSigmaATVec::Array{Float64,1}; SigmaA::Array{Float64,2}
+    A1Hat::Array{Float64,2}; A2Hat::Array{Float64,2}; A3Hat::Array{Float64,2}
+    BHat::Array{Float64,2}; SigmaB::Array{Float64,2}
+    CA::Array{Float64,1}; alpha::Array{Float64,1}; beta::Array{Float64,1}
+    CA1::Array{Float64,1}; alpha01::Float64; beta01::Float64; alpha1::Float64; beta1::Array{Float64,1}
+    CA2::Array{Float64,1}; alpha02::Float64; beta02::Float64; alpha2::Float64; beta2::Array{Float64,1}
+    CA3::Array{Float64,1}; alpha03::Float64; beta03::Float64; alpha3::Float64; beta3::Array{Float64,1}
+    CB::Array{Float64,1}; gamma0::Float64; delta0::Float64; gamma::Float64; delta::Array{Float64,1}
+    sigmaHat::Float64; eta0::Float64; zeta0::Float64; eta::Float64; zeta::Float64
+    sigmaVecHat::Array{Float64,1}; etaVec::Array{Float64,1}; zetaVec::Array{Float64,1}
+    YHat::Array{Float64,2}; trYTY::Float64
+    vbmf_trial_parameters() = new()
+end
+
+# (m, h)-interleaved vector <-> the three per-group vectors (A1: columns 1:H0, all rows; A2 / A3: the other columns of rows
+# 1:M0 / M0+1:M), src/vbmf_trial.jl:160-190
+function trial_split(v, M, H, H0, M0)
+    a = reshape(v, H, M)
+    return vec(a[1:H0, :]), vec(a[H0+1:end, 1:M0]), vec(a[H0+1:end, M0+1:end])
+end
+function trial_join(v1, v2, v3, M, H, H0, M0)
+    H1 = H - H0
+    return vec(vcat(reshape(v1, H0, M), hcat(reshape(v2, H1, M0), reshape(v3, H1, M - M0))))
+end
+
+"src/vbmf_trial.jl:139-226"
+function vbmf_trial_init(Y::Array{Float64,2}, H::Int, H0::Int, M0::Int; ca = 1.0, alpha0 = 1e-10, beta0 = 1e-10, cb = 1.0,
+                         gamma0 = 1e-10, delta0 = 1e-10, sigma = 1.0, eta0 = 1e-10, zeta0 = 1e-10)
+    H < H0 && error("H must be at least H0!")
+    p = vbmf_trial_parameters(); L, M = size(Y); H1 = H - H0; M1 = M - M0
+    p.L, p.M, p.M0, p.M1, p.H, p.MH, p.H0, p.H1 = L, M, M0, M1, H, M * H, H0, H1
+    p.AHat = randn(M, H); p.ATVecHat = reshape(permutedims(p.AHat), M * H); p.diagSigmaATVec = ones(M * H); p.SigmaA = zeros(H, H)
+    p.A1Hat, p.A2Hat, p.A3Hat = p.AHat[:, 1:H0], p.AHat[1:M0, H0+1:end], p.AHat[M0+1:end, H0+1:end]
+    p.BHat = randn(L, H); p.SigmaB = zeros(H, H)
+    p.CA1, p.CA2, p.CA3 = ca * ones(M * H0), ca * ones(M0 * H1), ca * ones(M1 * H1)
+    p.CA = trial_join(p.CA1, p.CA2, p.CA3, M, H, H0, M0)
+    p.alpha01 = p.alpha02 = p.alpha03 = alpha0; p.beta01 = p.beta02 = p.beta03 = beta0
+    p.alpha1 = p.alpha2 = p.alpha3 = alpha0 + 0.5
+    p.beta1, p.beta2, p.beta3 = beta0 * ones(M * H0), beta0 * ones(M0 * H1), beta0 * ones(M1 * H1)
+    p.alpha = [p.alpha1, p.alpha2, p.alpha3]; p.beta = trial_join(p.beta1, p.beta2, p.beta3, M, H, H0, M0)
+    p.CB = cb * ones(H); p.gamma0, p.delta0, p.gamma, p.delta = gamma0, delta0, gamma0 + L / 2, delta0 * ones(H)
+    p.sigmaHat, p.eta0, p.zeta0, p.eta, p.zeta = sigma, eta0, zeta0, eta0 + L * M / 2, zeta0
+    p.sigmaVecHat, p.etaVec, p.zetaVec = sigma * ones(L), (eta0 + M / 2) * ones(L), zeta0 * ones(L)
+    p.YHat = L * M <= (1 << 24) ? p.BHat * p.AHat' : Array{Float64}(undef, 0, 0)
+    p.trYTY = sum(abs2, Y)
+    return p
+end
+
+"vbmf_trial! -- src/vbmf_trial.jl:528-604 (returns d); est_priors: the six hyper-prior fits of :442-507 run on the device"
+function vbmf_trial!(Y::Array{Float64,2}, p::vbmf_trial_parameters, niter::Int; eps::Float64 = 1e-6, diag_var::Bool = false,
+                     full_cov::Bool = false, logdir = "", desc = "", verb = false, est_priors = true, est_cb::Bool = true)
+    full_cov && (diag_var || p.H > 64) && error("full_cov=true is built for diag_var=false and H <= 64")
+    logdir == "" || error("trajectory logging lives in the Python host (data_manip.py)")
+    c = sparse_ctx_for(Y, p.H, diag_var; variant = diag_var ? 6 : 4)          # VBMF_VARIANT_TRIAL_DIAGVAR / _TRIAL_DIAG
+    hy = Ref(SparseHyper(p.alpha01, p.beta01, p.gamma0, p.delta0, p.eta0, p.zeta0))
+    chk(c.h, ccall((:vbmf_sparse_set_state, libvbmf), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64},
+         Ptr{Float64}, Float64, Float64, Ref{SparseHyper}, Ptr{Int64}, Int64, Int64),
+        c.h, p.ATVecHat, p.diagSigmaATVec, p.CA, p.beta, p.BHat, p.L, p.SigmaB, p.CB, p.delta, p.sigmaHat, p.zeta, hy,
+        C_NULL, 0, 0))
+    pri = Float64[p.alpha01, p.beta01, p.alpha02, p.beta02, p.alpha03, p.beta03, p.alpha1, p.alpha2, p.alpha3]
+    chk(c.h, ccall((:vbmf_trial_set_priors, libvbmf), Cint, (Ptr{Cvoid}, Int64, Int64, Ptr{Float64}), c.h, p.H0, p.M0, pri))
+    diag_var ? chk(c.h, ccall((:vbmf_sparse_set_noise_rows, libvbmf), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Float64),
+                              c.h, p.sigmaVecHat, p.zetaVec, p.etaVec[1])) : set_full_cov!(c, p, full_cov)
+    iters = Ref{Int64}(0); d = Ref{Float64}(0.0)
+    chk(c.h, ccall((:vbmf_trial_run, libvbmf), Cint, (Ptr{Cvoid}, Int64, Float64, Cint, Cint, Ref{Int64}, Ref{Float64}, Ptr{Float64}),
+                   c.h, niter, eps, est_cb, est_priors, iters, d, C_NULL))
+    n = p.M * p.H
+    a = Array{Float64}(undef, n); ds = similar(a); ca = similar(a); be = similar(a); sa = Array{Float64}(undef, p.H)
+    B = Array{Float64}(undef, p.L, p.H); SB = Array{Float64}(undef, p.H, p.H); cb = Array{Float64}(undef, p.H); dl = similar(cb)
+    sh = Ref{Float64}(0.0); ze = Ref{Float64}(0.0)
+    chk(c.h, ccall((:vbmf_sparse_get_state, libvbmf), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Float64},
+         Ptr{Float64}, Ptr{Float64}, Ref{Float64}, Ref{Float64}),
+        c.h, a, ds, ca, be, sa, B, p.L, SB, cb, dl, sh, ze))
+    p.ATVecHat, p.diagSigmaATVec, p.CA, p.beta = a, ds, ca, be
+    p.AHat = permutedims(reshape(a, p.H, p.M))
+    p.A1Hat, p.A2Hat, p.A3Hat = p.AHat[:, 1:p.H0], p.AHat[1:p.M0, p.H0+1:end], p.AHat[p.M0+1:end, p.H0+1:end]
+    p.CA1, p.CA2, p.CA3 = trial_split(ca, p.M, p.H, p.H0, p.M0); p.beta1, p.beta2, p.beta3 = trial_split(be, p.M, p.H, p.H0, p.M0)
+    pull_SigmaA!(c, p)
+    p.BHat, p.SigmaB, p.CB, p.delta = B, SB, cb, dl
+    if diag_var
+        s = Array{Float64}(undef, p.L); z = similar(s)
+        chk(c.h, ccall((:vbmf_sparse_get_noise_rows, libvbmf), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), c.h, s, z))
+        p.sigmaVecHat, p.zetaVec = s, z
+    else
+        p.sigmaHat, p.zeta = sh[], ze[]
+    end
+    H0r = Ref{Int64}(0); M0r = Ref{Int64}(0); pr = Array{Float64}(undef, 9)
+    chk(c.h, ccall((:vbmf_trial_get_priors, libvbmf), Cint, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}, Ptr{Float64}), c.h, H0r, M0r, pr))
+    p.alpha01, p.beta01, p.alpha02, p.beta02, p.alpha03, p.beta03, p.alpha1, p.alpha2, p.alpha3 = pr
+    p.alpha = [p.alpha1, p.alpha2, p.alpha3]
+    p.L * p.M <= (1 << 24) && (p.YHat = p.BHat * p.AHat')                                       # :590
     verb && print("Factorization finished after ", iters[], " iterations, eps = ", d[], "\n")
     return d[]
 end
