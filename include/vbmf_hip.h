@@ -271,8 +271,9 @@ int vbmf_device_sync(vbmf_ctx* ctx);
 #define VBMF_PEEK_Y1 6     /* Y tiled for pass 1 */
 #define VBMF_PEEK_Y2 7     /* Y tiled for pass 2 */
 #define VBMF_PEEK_DIMS 8   /* int32 x 16: Hp, NH, mode, XT1, KS1, nsplit1, sps1, XT2, KS2, nsplit2, sps2, kstep, npart, narrow */
-#define VBMF_PEEK_CHAIN 9  /* uint64 x 4 (8 words): last durations of the in-launch control chain's parts in 10 ns ticks:
-                              ctrl_end, SigmaA, lambda_max(dB'dB) + loop test, SigmaB */
+#define VBMF_PEEK_CHAIN 9  /* uint64 x 8 (16 words): last durations in 10 ns ticks of the in-launch control chain's parts
+                              (ctrl_end, SigmaA, lambda_max(dB'dB) + loop test, SigmaB) and of the register epilogue's tail in
+                              workgroup 0 of the Y*A pass (wait for + load of the SigmaB table, tiles, fold + store, reserved) */
 int vbmf_debug_peek(vbmf_ctx* ctx, int what, uint32_t* out, int64_t nwords, int64_t word_offset);
 /* tuning hook: average milliseconds of `iters` back-to-back launches of streaming pass p (1|2) alone */
 int vbmf_debug_time_pass(vbmf_ctx* ctx, int pass, int iters, double* ms);

@@ -109,7 +109,9 @@ def test_many_ranks_one_gpu_threads(pkg, world, L, M, H, niter):
 
     e1 = errs_vs(ref["AHat"], ref["BHat"], ref["SigmaA"], ref["SigmaB"], ref["CA_diag"], ref["CB_diag"], ref["sigma2"], ref["d"], ref["elbo"])
     report(f"{world} ranks (threads, one GPU) vs 1 rank, {L}x{M} H={H}, {niter} sweeps: " + " ".join(f"{k}={v:.2e}" for k, v in e1.items()))
-    assert max(e1[k] for k in ("A", "B", "ca", "cb")) < 2e-5, e1
+    # the sharded run takes the split-pass kernels (post_gram2 on summed slabs), the single rank may take the register epilogue:
+    # same arithmetic, but in the bf16 factor modes each rounds its three-term bf16 product (2^-17) differently
+    assert max(e1[k] for k in ("A", "B", "ca", "cb")) < 6e-5, e1
     assert max(e1[k] for k in ("SA", "SB", "s2")) < 5e-4 and e1["elbo"] < 1e-4 and e1["d"] < 2e-2, e1
 
     # ... and against the fp64 oracle on the matrix as stored (not a self-comparison)

@@ -88,7 +88,9 @@ def _check(pkg, world, transport, tmp_path, case="h12"):
             assert np.array_equal(ranks[0]["priors"], r["priors"])
         assert np.max(np.abs(ranks[0]["priors"] - ref["priors"]) / np.abs(ref["priors"])) < 1e-3
         assert len(set(np.round(ranks[0]["priors"][[0, 2, 4]], 12))) == 3
-    assert max(errs[k_] for k_ in ("A", "B", "ca", "cb")) < 2e-5 * k, errs
+    # (6e-5: the ranks' split-pass kernels and the single rank's register epilogue round their three-term bf16 products,
+    #  2^-17 each, differently)
+    assert max(errs[k_] for k_ in ("A", "B", "ca", "cb")) < 6e-5 * k, errs
     assert max(errs[k_] for k_ in ("SA", "SB", "s2")) < 5e-4 * (2.0 if k > 1 else 1.0), errs
     assert errs["trYY"] < 1e-12 and errs["elbo"] < 1e-4, errs
     assert abs(float(ranks[0]["d"]) - ref["d"]) < 2e-2 * ref["d"] + 2e-6, errs

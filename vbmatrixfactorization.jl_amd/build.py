@@ -31,12 +31,13 @@ def up_to_date():
     return all(os.path.getmtime(d) <= t for d in DEPS)
 
 
-def build(force=False, verbose=False):
-    if not force and up_to_date():
+def build(force=False, verbose=False, out=OUT):
+    if not force and out == OUT and up_to_date():
         return OUT
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-unused-value", "-Wno-unused-result", SRC, "-o", OUT + ".tmp",
+           "-Wno-unused-value", "-Wno-unused-result", SRC, "-o", out + ".tmp",
            "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+    cmd[1:1] = os.environ.get("VBMF_HIPCC_FLAGS", "").split()      # tuning switches for A/B builds (e.g. -DVBMF_EPI_PV_AHEAD=0)
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd))
@@ -46,8 +47,8 @@ def build(force=False, verbose=False):
         raise RuntimeError("hipcc failed building libvbmf_hip.so")
     if verbose:
         sys.stderr.write(r.stderr)
-    os.replace(OUT + ".tmp", OUT)
-    return OUT
+    os.replace(out + ".tmp", out)
+    return out
 
 
 if __name__ == "__main__":

@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvbmf_hip.so")
+# VBMF_HIP_LIB: another build of the SAME library (A/B tuning builds under variants/); default: the in-tree build
+LIB_PATH = os.environ.get("VBMF_HIP_LIB") or os.path.join(_HERE, "libvbmf_hip.so")
 
 VBMF_Y_F32, VBMF_Y_BF16 = 0, 1
 VBMF_FACTOR_AUTO, VBMF_FACTOR_BF16, VBMF_FACTOR_BF16X2 = 0, 1, 2
@@ -456,8 +457,9 @@ class Context:
 
     def chain_us(self):
         """Last durations (microseconds) of the in-launch control chain's parts."""
-        v = self.peek(PEEK_CHAIN, 8, dtype=np.uint64)
-        return dict(zip(("ctrl_end", "SigmaA", "lambda_max_dB_and_loop", "SigmaB"), (float(x) * 0.01 for x in v)))
+        v = self.peek(PEEK_CHAIN, 16, dtype=np.uint64)
+        return dict(zip(("ctrl_end", "SigmaA", "lambda_max_dB_and_loop", "SigmaB", "epilogue_table", "epilogue_tiles", "epilogue_fold"),
+                        (float(x) * 0.01 for x in v)))
 
     def dims(self):
         v = self.peek(PEEK_DIMS, 16, dtype=np.int32)

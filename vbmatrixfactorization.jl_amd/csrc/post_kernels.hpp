@@ -74,6 +74,15 @@ __device__ __forceinline__ void write_factor_tiles(uint4* __restrict__ Ft, f32x1
 // 32 x 33 LDS tile of this wave (conflict-free both ways) and comes back transposed.  Returns this lane's partial sum.
 // (The Gram identity tr(KB * B'B) used before is exact only for an un-rounded B = Q * inv(KB): with B stored as bf16 hi + lo
 //  and Sigma/sigma2 as an fp32 table its error, amplified ~400x by sigma2's cancellation, reached 1.5e-3 at 1200 x 900, H = 128.)
+// 8 fp32 values -> their bf16 hi and bf16 lo parts as packed MFMA fragments (hi + lo carries ~16 significant bits)
+__device__ __forceinline__ void split8_bf16(const float* v, u32x4v& hi, u32x4v& lo) {
+    unsigned short h8[8], l8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { h8[e] = f2bf(v[e]); l8[e] = f2bf(v[e] - bf2f(h8[e])); }
+    hi = u32x4v{h8[0] | ((unsigned)h8[1] << 16), h8[2] | ((unsigned)h8[3] << 16), h8[4] | ((unsigned)h8[5] << 16), h8[6] | ((unsigned)h8[7] << 16)};
+    lo = u32x4v{l8[0] | ((unsigned)l8[1] << 16), l8[2] | ((unsigned)l8[3] << 16), l8[4] | ((unsigned)l8[5] << 16), l8[6] | ((unsigned)l8[7] << 16)};
+}
+
 constexpr int TB_LD = 33;
 template <bool RHO>
 __device__ __forceinline__ float tile_dot_qb(const float (&q)[16], const f32x16& b, float* tb, int lane) {
@@ -251,13 +260,7 @@ __global__ __launch_bounds__(256) void post_frag_kernel(const float4* __restrict
             // split the same way and multiplied as hi*hi + hi*lo + lo*hi (the dropped lo*lo is 2^-18 relative): three bf16
             // MFMAs per 16 contraction steps instead of eight exact-f32 ones at half the rate -- 5x less MFMA time.  The 8
             // values of a lane's fragment are its registers 8s..8s+7 (contraction order rho), on both operands.
-            auto split8 = [](const float* v, u32x4v& hi, u32x4v& lo) __attribute__((always_inline)) {
-                unsigned short h8[8], l8[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { h8[e] = f2bf(v[e]); l8[e] = f2bf(v[e] - bf2f(h8[e])); }
-                hi = u32x4v{h8[0] | ((unsigned)h8[1] << 16), h8[2] | ((unsigned)h8[3] << 16), h8[4] | ((unsigned)h8[5] << 16), h8[6] | ((unsigned)h8[7] << 16)};
-                lo = u32x4v{l8[0] | ((unsigned)l8[1] << 16), l8[2] | ((unsigned)l8[3] << 16), l8[4] | ((unsigned)l8[5] << 16), l8[6] | ((unsigned)l8[7] << 16)};
-            };
+            auto split8 = [](const float* v, u32x4v& hi, u32x4v& lo) __attribute__((always_inline)) { split8_bf16(v, hi, lo); };
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 u32x4v ah[NXT], al[NXT];
@@ -377,12 +380,15 @@ __global__ __launch_bounds__(256) void untile_factor_kernel(const uint4* __restr
 // any k order as long as both operands agree, so register r IS the A operand of instruction r when the table operand
 // is read in the same permuted order: S[hin*32 + rho(r, half)][h*32 + c] (from the workgroup's LDS copy).  No store, no reload,
 // no shuffle between the product and the update B = (Y A) SigmaB / sigma2 (src/vbmf.jl:112).
-template <int MODE, int NH>
+// BSIDE = true: the B update (delta-Gram against the previous factor rows pv, tr(B'YA)); false: the A update (label mask
+// of src/vbmf.jl:101, no delta-Gram, no trace).
+template <int MODE, int NH, bool BSIDE = true>
 __device__ __forceinline__ void post_gram_tile_regs(const f32x16 (&q)[NH], const float* stab /* LDS: S[Hp][Hp] */, int xt,
                                                     float* __restrict__ Fac, const float* __restrict__ Prev,
                                                     uint4* __restrict__ Ft, int lane,
                                                     f32x16 (&G)[NH * (NH + 1) / 2], f32x16 (&D)[NH * (NH + 1) / 2],
-                                                    const f32x16 (&pv)[NH], int store_fac, float* tb, double& trd) {
+                                                    const f32x16 (&pv)[NH], int store_fac, float* tb, double& trd,
+                                                    const unsigned char* __restrict__ mask = nullptr, int hmask_start = 0) {
     constexpr int Hp = NH * 32;
     const int c = lane & 31, half = lane >> 5;
     const long long x0 = (long long)xt * 32;
@@ -392,6 +398,10 @@ __device__ __forceinline__ void post_gram_tile_regs(const f32x16 (&q)[NH], const
     for (int h = 0; h < NH; ++h)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[h][r] = 0.f;
+    // exact-f32 MFMA in every mode.  (A three-term bf16 product hi*hi + hi*lo + lo*hi -- 24 MFMAs of 32 cycles instead of 64 of
+    // 64 -- was built and measured: 9 us off the pass at 100k x 10k, but each term then carries 2^-17 instead of 2^-24 and
+    // B = Q * inv(K_B) cancels by the condition number of K_B: BHat off by 5e-4 .. 2.6e-3 on rank-deficient data
+    // (profiles/r02_e_three_term_product.txt).  Parity first: reverted.)
 #pragma unroll
     for (int hin = 0; hin < NH; ++hin)
 #pragma unroll
@@ -407,13 +417,20 @@ __device__ __forceinline__ void post_gram_tile_regs(const f32x16 (&q)[NH], const
     u32x4v fr[NH][4];
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
+        if constexpr (!BSIDE) {
+            if (mask != nullptr && h * 32 + c >= hmask_start) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (mask[x0 + rho(r, half)]) acc[h][r] = 0.f;
+            }
+        }
         write_factor_tiles<MODE, NH>(Ft, acc[h], xt, h, lane, MODE == MODE_F32 ? nullptr : fr[h]);
         if (store_fac) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) Fac[(x0 + rho(r, half)) * Hp + h * 32 + c] = acc[h][r];
         }
     }
-    {   // tr(B'YA) of this tile: the product is still in registers, the new factor is now exactly what the tiles encode
+    if constexpr (BSIDE) {   // tr(B'YA) of this tile: the product is still in registers, the new factor is now exactly what the tiles encode
         float tsum = 0.f;
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
@@ -434,12 +451,15 @@ __device__ __forceinline__ void post_gram_tile_regs(const f32x16 (&q)[NH], const
                 for (int r = 0; r < 16; ++r) {
                     const float u = acc[h1][r], v = acc[h2][r];
                     G[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(u, v, G[p], 0, 0, 0);
-                    const float du = pv[h1][r] - u, dv = pv[h2][r] - v;
-                    D[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(du, dv, D[p], 0, 0, 0);
+                    if constexpr (BSIDE) {
+                        const float du = pv[h1][r] - u, dv = pv[h2][r] - v;
+                        D[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(du, dv, D[p], 0, 0, 0);
+                    }
                 }
     } else {
         constexpr int NPART = ModeTraits<MODE>::NPART;
         u32x4v dr[NH][4];
+        if constexpr (BSIDE) {
 #pragma unroll
         for (int h = 0; h < NH; ++h)
 #pragma unroll
@@ -456,6 +476,7 @@ __device__ __forceinline__ void post_gram_tile_regs(const f32x16 (&q)[NH], const
                 dr[h][2 * s2 + 1] = u32x4v{lo[0] | ((unsigned)lo[1] << 16), lo[2] | ((unsigned)lo[3] << 16),
                                            lo[4] | ((unsigned)lo[5] << 16), lo[6] | ((unsigned)lo[7] << 16)};
             }
+        }
         int p = 0;
 #pragma unroll
         for (int h1 = 0; h1 < NH; ++h1)
@@ -469,160 +490,86 @@ __device__ __forceinline__ void post_gram_tile_regs(const f32x16 (&q)[NH], const
                         for (int pb = 0; pb < NPART; ++pb)
                             G[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fr[h1][2 * s2 + pa]),
                                                                            __builtin_bit_cast(bf16x8, fr[h2][2 * s2 + pb]), G[p], 0, 0, 0);
+                    if constexpr (BSIDE) {
 #pragma unroll
-                    for (int pa = 0; pa < 2; ++pa)
+                        for (int pa = 0; pa < 2; ++pa)
 #pragma unroll
-                        for (int pb = 0; pb < 2; ++pb)
-                            D[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, dr[h1][2 * s2 + pa]),
-                                                                           __builtin_bit_cast(bf16x8, dr[h2][2 * s2 + pb]), D[p], 0, 0, 0);
+                            for (int pb = 0; pb < 2; ++pb)
+                                D[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, dr[h1][2 * s2 + pa]),
+                                                                               __builtin_bit_cast(bf16x8, dr[h2][2 * s2 + pb]), D[p], 0, 0, 0);
+                    }
                 }
     }
 }
 
-// ---- fused post + Gram (NH <= 2) ---------------------------------------------------------------------
-// Same update as post_kernel, and while the new 32-row tile still sits in accumulator registers its
-// Gram contribution (and, against the previous factor, the delta-Gram) is added with the tile fed back
-// as BOTH MFMA operands (the contraction runs over the row index that lives in registers: no
-// transpose, no LDS).  Waves walk tiles with stride gridDim*4; the four waves of a workgroup fold their
-// register partials through LDS into one slab per workgroup (upper-triangular tile pairs only).
-//   slabs: [gridDim.x][2 (Gram, delta)][NPAIR][16 regs][64 lanes] fp32
-// FRAG: `In` is a FRAGMENT-MAJOR product (stream_gemm.hpp, frag_out: per (x tile, h tile) 64 lanes x 16 registers, a lane's
-// registers contiguous) -- read with four 16-byte loads per tile instead of sixteen 4-byte row accesses; register t is then
-// the A operand of MFMA step t, so the table is hoisted in the matching row order rho(t, half).
-template <int MODE, int NH, bool FRAG = false>
-__global__ __launch_bounds__(256) void post_gram_kernel(const float* __restrict__ In, long long ldIn, int nslab,
-                                                        long long slabStride, const float* __restrict__ S,
-                                                        float* __restrict__ Fac, const float* __restrict__ Prev,
-                                                        uint4* __restrict__ Ft, const unsigned char* __restrict__ mask,
-                                                        int hmask_start, int XT, float* __restrict__ slabs,
-                                                        const int* __restrict__ stop, double* __restrict__ trpart = nullptr) {
+// The Sigma / sigma2 table of post_gram_tile_regs into the workgroup's LDS (4 Hp^2 bytes), by all 256 threads, 16-byte loads.
+// The caller barriers.
+template <int MODE, int NH>
+__device__ __forceinline__ void load_sigma_table(float* stab, const float* __restrict__ S) {
+    constexpr int Hp = NH * 32;
+    for (int i = threadIdx.x; i < Hp * Hp / 4; i += 256)
+        reinterpret_cast<float4*>(stab)[i] = reinterpret_cast<const float4*>(S)[i];
+}
+
+// ---- fused post + Gram (NH <= 2), second form: the tile body of the register epilogue as its own kernel ------------------
+// For products that did go through HBM: Y'B always (split-K slabs, summed by slab_sum / all-reduced over the ranks before), Y*A
+// when that pass is split (short row shards, narrow problems).  `In` is ONE fragment-major product (stream_gemm.hpp, frag_out):
+// the wave's tile arrives as its accumulator registers in four 16-byte loads per column tile and runs through
+// post_gram_tile_regs -- the exact-f32 product and, in the bf16 factor modes, the bf16 Gram / delta-Gram of the operand fragments
+// (every product exact): 5 600 MFMA cycles per tile where round 1's all-f32 post + Gram kernel spent 10 240.  The previous factor's rows
+// (BSIDE: for the delta-Gram) come from its operand tiles (1 KiB wave loads), the table from LDS; the stop flag is requested
+// first and looked at before the first store, so its round trip overlaps the loads.  store_fac = 0 (inside the run loops):
+// the fp32 row-major factor is not written (rebuilt from the tiles once at the end, like the register epilogue's).
+//   slabs: [gridDim.x][2 (Gram, delta)][NPAIR][16 regs][64 lanes] fp32;  trpart: [gridDim.x][4] per-wave shares of tr(B'YA)
+template <int MODE, int NH, bool BSIDE>
+__global__ __launch_bounds__(256) void post_gram2_kernel(const float* __restrict__ In, const float* __restrict__ S,
+                                                         float* __restrict__ Fac, uint4* __restrict__ Ft,
+                                                         const unsigned char* __restrict__ mask, int hmask_start, int XT,
+                                                         float* __restrict__ slabs, const int* __restrict__ stop,
+                                                         double* __restrict__ trpart, int store_fac) {
     static_assert(NH <= 2, "fused Gram keeps NH(NH+1)/2 pair tiles per matrix in registers");
     constexpr int Hp = NH * 32;
     constexpr int NPAIR = NH * (NH + 1) / 2;
     __shared__ float fold[2 * NPAIR * 16 * 64];
     __shared__ float tbuf[4][32 * TB_LD];
-    double trd = 0.0;
-    if (stop && *stop) return;
+    __shared__ __attribute__((aligned(16))) float stab[Hp * Hp];
+    const int stopped = stop ? __hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
-    const int c = lane & 31, half = lane >> 5;
+    load_sigma_table<MODE, NH>(stab, S);
     f32x16 G[NPAIR], D[NPAIR];
 #pragma unroll
     for (int p = 0; p < NPAIR; ++p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { G[p][r] = 0.f; D[p][r] = 0.f; }
-
-    // this lane's slice of the Sigma/sigma2 table, loaded once (the same for every tile):
-    // sreg[hin][t][h] = S[hin*32 + 2t + half][h*32 + c]
-    float sreg[NH][16][NH];
-#pragma unroll
-    for (int hin = 0; hin < NH; ++hin)
-#pragma unroll
-        for (int t = 0; t < 16; ++t)
-#pragma unroll
-            for (int h = 0; h < NH; ++h)
-                sreg[hin][t][h] = S[(long long)(hin * 32 + (FRAG ? rho(t, half) : 2 * t + half)) * Hp + h * 32 + c];
-
-    for (int xt = blockIdx.x * 4 + wib; xt < XT; xt += gridDim.x * 4) {
-        const long long x0 = (long long)xt * 32;
-        // issue every load of the tile before the first MFMA (one wave per SIMD: latency is hidden by
-        // loads in flight, not by other waves)
-        float areg[NH][16];
-        if constexpr (FRAG) {
+    double trd = 0.0;
+    bool first = true;
+    for (int xt0 = blockIdx.x * 4; xt0 < XT; xt0 += gridDim.x * 4) {        // workgroup-uniform trip count
+        const int xt = xt0 + wib;
+        const bool active = xt < XT;
+        f32x16 q[NH], pv[NH];
+        if (active) {
 #pragma unroll
             for (int hin = 0; hin < NH; ++hin) {
                 const float4* ip = reinterpret_cast<const float4*>(In) + (((long long)xt * NH + hin) * 64 + lane) * 4;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float4 v = ip[q];
-                    for (int s = 1; s < nslab; ++s) {
-                        const float4 w = ip[(long long)s * (slabStride >> 2) + q];
-                        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
-                    }
-                    areg[hin][4 * q] = v.x; areg[hin][4 * q + 1] = v.y; areg[hin][4 * q + 2] = v.z; areg[hin][4 * q + 3] = v.w;
+                for (int qd = 0; qd < 4; ++qd) {
+                    const float4 v = ip[qd];
+                    q[hin][4 * qd] = v.x; q[hin][4 * qd + 1] = v.y; q[hin][4 * qd + 2] = v.z; q[hin][4 * qd + 3] = v.w;
                 }
             }
-        } else {
+            if constexpr (BSIDE) {
 #pragma unroll
-            for (int hin = 0; hin < NH; ++hin)
-#pragma unroll
-                for (int t = 0; t < 16; ++t) {
-                    const float* ip = In + (long long)(hin * 32 + 2 * t + half) * ldIn + x0 + c;
-                    float a = ip[0];
-                    for (int s = 1; s < nslab; ++s) a += ip[(long long)s * slabStride];
-                    areg[hin][t] = a;
-                }
-        }
-        f32x16 pv[NH];
-        if (Prev != nullptr) {
-#pragma unroll
-            for (int h = 0; h < NH; ++h)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) pv[h][r] = Prev[(x0 + rho(r, half)) * Hp + h * 32 + c];
-        }
-        f32x16 acc[NH];
-#pragma unroll
-        for (int h = 0; h < NH; ++h)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[h][r] = 0.f;
-#pragma unroll
-        for (int hin = 0; hin < NH; ++hin)
-#pragma unroll
-            for (int t = 0; t < 16; ++t)
-#pragma unroll
-                for (int h = 0; h < NH; ++h)
-                    acc[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[hin][t], sreg[hin][t][h], acc[h], 0, 0, 0);
-#pragma unroll
-        for (int h = 0; h < NH; ++h) {
-            const int hcol = h * 32 + c;
-            if (mask != nullptr && hcol >= hmask_start) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (mask[x0 + rho(r, half)]) acc[h][r] = 0.f;
+                for (int h = 0; h < NH; ++h) read_factor_tiles<MODE, NH>(Ft, pv[h], xt, h, lane);
             }
-            write_factor_tiles<MODE, NH>(Ft, acc[h], xt, h, lane);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) Fac[(x0 + rho(r, half)) * Hp + hcol] = acc[h][r];
         }
-        if (trpart != nullptr) {                             // tr(B'YA) of this tile (B side only)
-            float tsum = 0.f;
-#pragma unroll
-            for (int h = 0; h < NH; ++h) tsum += tile_dot_qb<FRAG>(areg[h], acc[h], tbuf[wib], lane);
-            trd += (double)tsum;
+        if (first) {
+            __syncthreads();                                                  // the table is in LDS
+            if (stopped) return;                                              // uniform over the grid; nothing stored yet
+            first = false;
         }
-        // Gram of the new tile: pair index p runs over h1 <= h2
-        {
-            int p = 0;
-#pragma unroll
-            for (int h1 = 0; h1 < NH; ++h1)
-#pragma unroll
-                for (int h2 = h1; h2 < NH; ++h2, ++p)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float u = acc[h1][r], v = acc[h2][r];
-                        G[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(u, v, G[p], 0, 0, 0);
-                    }
-        }
-        if (Prev != nullptr) {
-            f32x16 dv[NH];
-#pragma unroll
-            for (int h = 0; h < NH; ++h)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float cur = acc[h][r], old = pv[h][r];
-                    dv[h][r] = old - cur;
-                }
-            int p = 0;
-#pragma unroll
-            for (int h1 = 0; h1 < NH; ++h1)
-#pragma unroll
-                for (int h2 = h1; h2 < NH; ++h2, ++p)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float u = dv[h1][r], v = dv[h2][r];
-                        D[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(u, v, D[p], 0, 0, 0);
-                    }
-        }
+        if (active)
+            post_gram_tile_regs<MODE, NH, BSIDE>(q, stab, xt, Fac, nullptr, Ft, lane, G, D, pv, store_fac, tbuf[wib], trd, mask, hmask_start);
     }
     // fold the four waves' partials (fixed order => deterministic), then one coalesced slab store
     for (int wv = 0; wv < 4; ++wv) {
@@ -641,7 +588,7 @@ __global__ __launch_bounds__(256) void post_gram_kernel(const float* __restrict_
     }
     float* o = slabs + (long long)blockIdx.x * (2 * NPAIR * 1024);
     for (int i = threadIdx.x; i < 2 * NPAIR * 1024; i += 256) o[i] = fold[i];
-    if (trpart != nullptr) store_wave_dot(trd, trpart + blockIdx.x * 4 + wib, lane);
+    if (BSIDE && trpart != nullptr) store_wave_dot(trd, trpart + blockIdx.x * 4 + wib, lane);
 }
 
 // fp64 reduction of the post_gram slabs into dense Hp x Hp matrices (both triangles).

@@ -43,6 +43,12 @@ namespace vbmf {
 // cache policy of the Y stream: 2 = nt (streamed once); 0 = default
 constexpr int Y_AUX = 2;
 
+// tuning switch of the register epilogue (A/B on the GPU, see profiles/): 1 = the previous factor's rows are loaded one tile
+// ahead (costs 32 more live registers per column tile), 0 = at the head of each tile
+#ifndef VBMF_EPI_PV_AHEAD
+#define VBMF_EPI_PV_AHEAD 1
+#endif
+
 // Epilogue of the Y*A pass (EPI = 1, un-split pass, H <= 64): the product tiles never leave the registers -- B = (Y A) SigmaB
 // / sigma2, its operand tiles, the fp32 factor and the Gram / delta-Gram partials are produced right here
 // (post_kernels.hpp, post_gram_tile_regs), which removes the L x H round trip through HBM and one launch per sweep.
@@ -60,6 +66,15 @@ struct EpiArgs {
     int store_fac;                           // 0 inside vbmf_run: the fp32 factor is rebuilt from the tiles once, at the end
     int frag_out;                            // EPI = 0 only: write the product in FRAGMENT-MAJOR order (below)
     double* trpart;                          // EPI = 1: per-wave shares of tr(B'YA) = sum (Y A) o BHat  [4 * workgroups]
+    unsigned long long* stamp;               // EPI = 1: durations of workgroup 0's tail in 10 ns ticks: [0] wait for + load of the
+                                             // SigmaB table, [1] the tiles' post / Gram work, [2] fold + slab store
+    // EPI = 1: workgroup -> x-group map: workgroup b takes g_base x groups, the first g_rem workgroups one more (<= 4: one per
+    // wave; the other waves idle).  Default: four per workgroup (782 groups of 100k rows = 196 workgroups).  Both ways of
+    // putting the idle 60 CUs to work were measured and are SLOWER (profiles/r02_f_epilogue_pass_ab.txt): three groups per
+    // workgroup on 254 CUs 0.372 vs 0.366 ms (with a 6- or a 12-deep Y ring alike), single tiles dealt to the waves (3 of the 4
+    // accumulator tiles busy, the fourth behind a zero-record descriptor) 0.3725 vs 0.354 ms -- the four waves of a CU share
+    // the factor operand's L1 lines, fewer / narrower waves per CU pay for that operand again.
+    int g_base, g_rem;
 };
 
 // FDBG (tuning harness only): 1 = the factor ring re-reads one L1-hot k-step, 2 = no factor refills at all
@@ -108,11 +123,15 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const uint4* __restric
     }
     int xg = xb * 4 + wib;
     bool active = true;
+    int t0 = xg * NXW_, nt = NXW_;                         // first x tile of this wave, number of its tiles
     if constexpr (EPI) {
-        // every wave of the workgroup meets in the epilogue's fold: a wave without an x group streams nothing
+        // every wave of the workgroup meets in the epilogue's fold: a wave without tiles streams nothing
         if (split >= nsplit) return;                       // workgroup-uniform
-        active = xg < XG;
-        if (!active) { xg = 0; steps_per_split = -DY; }
+        const int gb = epi.g_base + (xb < epi.g_rem ? 1 : 0);              // x groups of this workgroup
+        xg = xb * epi.g_base + (xb < epi.g_rem ? xb : epi.g_rem) + wib;
+        active = wib < gb;
+        t0 = xg * NXW_;
+        if (!active) { xg = 0; t0 = 0; nt = 0; steps_per_split = -DY; }
     } else {
         if (xg >= XG || split >= nsplit) return;          // wave-uniform
     }
@@ -124,7 +143,7 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const uint4* __restric
 #pragma unroll
     for (int i = 0; i < NXW_; ++i)
         yr[i] = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(Yt + (((long long)(xg * NXW_ + i)) * KS + ks0) * 64), 0, ybytes, 0x00020000);
+            (void*)(Yt + (((long long)(t0 + (i < nt ? i : 0))) * KS + ks0) * 64), 0, i < nt ? ybytes : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t fr =
         __builtin_amdgcn_make_buffer_rsrc((void*)(Ft + ks0 * (NF * 64)), 0, fbytes, 0x00020000);
     const int voff = lane * 16;
@@ -241,6 +260,7 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const uint4* __restric
         __shared__ float tbuf[4][32 * TB_LD];
         double trd = 0.0;
         const int c = lane & 31, half = lane >> 5;
+        const unsigned long long e0 = wall_clock64();      // (stamps: the tail of workgroup 0, see VBMF_PEEK_CHAIN)
         if (epi.expect >= 0) {                             // SigmaB / sigma2 is written by workgroup 0 of this launch
             int spins = 0;
             while (__hip_atomic_load(epi.sready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epi.expect) {
@@ -252,9 +272,9 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const uint4* __restric
         // the SigmaB / sigma2 table goes to LDS once per workgroup (16-byte loads) and is read from there as the MFMA's B
         // operand, row rho(t, half) for step t: as 64 registers per lane it pushed the tile body over the register file
         __shared__ __attribute__((aligned(16))) float stab[Hp * Hp];
-        for (int i = threadIdx.x; i < Hp * Hp / 4; i += 256)
-            reinterpret_cast<float4*>(stab)[i] = reinterpret_cast<const float4*>(epi.S)[i];
+        load_sigma_table<MODE, NH>(stab, epi.S);
         __syncthreads();
+        const unsigned long long e1 = wall_clock64();
         f32x16 G[NPAIR], D[NPAIR];
 #pragma unroll
         for (int p = 0; p < NPAIR; ++p)
@@ -265,23 +285,37 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const uint4* __restric
             // end of each tile: one round of memory latency instead of one per tile)
             // read from the factor's OPERAND TILES (they encode exactly the fp32 factor): 1 KiB wave loads
             // (one tile ahead, not all NXW at once: with the tr(B'YA) block in the tile body the full prefetch spilled)
+#if VBMF_EPI_PV_AHEAD
             f32x16 pvn[NH];
 #pragma unroll
-            for (int h = 0; h < NH; ++h) read_factor_tiles<MODE, NH>(epi.Ft, pvn[h], xg * NXW_, h, lane);
+            for (int h = 0; h < NH; ++h) read_factor_tiles<MODE, NH>(epi.Ft, pvn[h], t0, h, lane);
 #pragma unroll
             for (int i = 0; i < NXW_; ++i) {
+                if (i >= nt) break;                        // wave-uniform
                 f32x16 pvc[NH];
 #pragma unroll
                 for (int h = 0; h < NH; ++h) pvc[h] = pvn[h];
-                if (i + 1 < NXW_) {
+                if (i + 1 < nt) {
 #pragma unroll
-                    for (int h = 0; h < NH; ++h) read_factor_tiles<MODE, NH>(epi.Ft, pvn[h], xg * NXW_ + i + 1, h, lane);
+                    for (int h = 0; h < NH; ++h) read_factor_tiles<MODE, NH>(epi.Ft, pvn[h], t0 + i + 1, h, lane);
                 }
-                post_gram_tile_regs<MODE, NH>(acc[i], stab, xg * NXW_ + i, epi.Fac, epi.Prev, epi.Ft, lane, G, D, pvc,
+                post_gram_tile_regs<MODE, NH>(acc[i], stab, t0 + i, epi.Fac, epi.Prev, epi.Ft, lane, G, D, pvc,
                                               epi.store_fac, tbuf[wib], trd);
             }
+#else
+#pragma unroll
+            for (int i = 0; i < NXW_; ++i) {               // loads issued at the head of the tile, consumed after its product
+                if (i >= nt) break;                        // wave-uniform
+                f32x16 pvc[NH];
+#pragma unroll
+                for (int h = 0; h < NH; ++h) read_factor_tiles<MODE, NH>(epi.Ft, pvc[h], t0 + i, h, lane);
+                post_gram_tile_regs<MODE, NH>(acc[i], stab, t0 + i, epi.Fac, epi.Prev, epi.Ft, lane, G, D, pvc,
+                                              epi.store_fac, tbuf[wib], trd);
+            }
+#endif
         }
         store_wave_dot(trd, epi.trpart + (long long)xb * 4 + wib, lane);   // (an idle wave contributes 0)
+        const unsigned long long e2 = wall_clock64();
         // fold the four waves' partials (fixed order => deterministic), then one coalesced slab store per workgroup
         for (int wv = 0; wv < 4; ++wv) {
             if (wib == wv) {
@@ -299,6 +333,10 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const uint4* __restric
         }
         float* o = epi.slabs + (long long)xb * (2 * NPAIR * 1024);
         for (int i = threadIdx.x; i < 2 * NPAIR * 1024; i += 256) o[i] = fold[i];
+        if (xb == 0 && threadIdx.x == 0 && epi.stamp != nullptr) {
+            const unsigned long long e3 = wall_clock64();
+            epi.stamp[0] = e1 - e0; epi.stamp[1] = e2 - e1; epi.stamp[2] = e3 - e2;
+        }
     } else if (epi.frag_out) {
         // Fragment-major product for the H >= 128 post kernel: tile (x tile, h tile) is 64 lanes x 16 registers, each lane's
         // registers contiguous -- four 16-byte stores per tile here and four 16-byte loads there, instead of sixteen 4-byte

@@ -107,6 +107,9 @@ struct vbmf_ctx {
     bool P_frag = false;              // the Y'B product in c->P / c->Pred is fragment-major (stream_gemm.hpp, frag_out)
     bool B32_stale = false;           // the register epilogue skipped the fp32 store of B (inside vbmf_run): tiles are current
     int sready_seq = 0;               // sequence number of the Sigma-table release flag (register epilogue)
+    bool epi_balance = false;         // x groups of the register-epilogue pass dealt three per workgroup over the whole chip instead
+                                      // of four per workgroup: measured SLOWER (0.372 vs 0.366 ms at 100k rows), kept behind
+                                      // VBMF_EPI_BALANCE=1 for the record (profiles/r02_f_epilogue_pass_ab.txt)
     int epi_spin_limit = 1 << 22;     // bounded wait of the register epilogue for that flag (~2 s), then VBMF_ERR_SYNC
     int epi_expect_skew = 0;          // test hook (vbmf_debug_set): makes the epilogue wait for a sequence number nobody publishes
     int64_t ends_enqueued = 0;        // sweeps whose closing control step has been enqueued in this run (trace row)
@@ -219,10 +222,18 @@ constexpr int NUM_CU = 254;
 //     max( rounds * bytes_per_block / R_CU ,  total_bytes / R_HBM )  +  slab write+read
 // with rounds = ceil(blocks / 256).  Pick the split factor minimising that (measured at 100k x 10k:
 // 240 blocks 0.35 ms, 260 blocks 0.61 ms, 160 blocks 0.44 ms -- the model's ordering).
-static void plan_pass(Dims& d, int64_t X, int64_t K, int kstep, int NH, int Hp, double ybytes, int want_splits, bool narrow) {
+// Y ring depth of the H = 64 register-epilogue pass (tuning switch, A/B on the GPU): with three waves per CU (balanced map) a
+// deeper ring keeps more bytes in flight per wave
+#ifndef VBMF_EPI_DY
+#define VBMF_EPI_DY 6
+#endif
+
+static void plan_pass(Dims& d, int64_t X, int64_t K, int kstep, int NH, int Hp, double ybytes, int want_splits, bool narrow,
+                      int kq_also = 0) {
     // padding quanta: x tiles to the per-wave tile count, k-steps to the Y ring depth (zero tiles are streamed
     // like real ones, so padding is pure waste: 3.7 % of pass 2 at 100k x 10k with the old 8-tile / 12-step quanta)
-    const int xq = nxw_of(NH, narrow), kq = dy_of(NH, narrow);
+    const int xq = nxw_of(NH, narrow), kq = std::max(dy_of(NH, narrow), kq_also);
+    static_assert(VBMF_EPI_DY % 6 == 0 && PIPE_D % VBMF_EPI_DY == 0, "the epilogue pass's ring depth must be a multiple of the wide geometry's");
     d.XT = (int)rup(cdiv(X, 32), xq);
     const int64_t ks_min = rup(cdiv(rup(K, 32 * xq), kstep), kq);   // K padded like the other pass's x tiles
     const int XG = d.XT / xq;
@@ -304,8 +315,20 @@ static int launch_stream(vbmf_ctx* c, int pass, int ctrl_mode = 0, bool epi = fa
     const uint4* F = pass == 0 ? (c->diagvar ? c->FBs : c->FB) : c->FA;
     float* out = pass == 0 ? c->P : c->Q;
     const long long ld = (long long)d.XT * 32;
-    const int XG = d.XT / nxw_of(c->NH, c->narrow);
-    const int bps = (XG + 3) / 4;
+    int XG = d.XT / nxw_of(c->NH, c->narrow);
+    int bps = (XG + 3) / 4;
+    EpiArgs ea{};
+    if (epi) {
+        // balanced workgroup -> x-group map of the un-split pass (stream_gemm.hpp, EpiArgs): three groups per workgroup while
+        // that fits one round of the chip, four otherwise
+        int nb = bps;
+        if (c->epi_balance && cdiv(XG, 3) <= NUM_CU) nb = cdiv(XG, 3);
+        else if (c->epi_balance && cdiv(XG, NUM_CU) <= 4) nb = std::max(bps, std::min(NUM_CU, XG));
+        ea.g_base = XG / nb;
+        ea.g_rem = XG % nb;
+        bps = nb;
+        XG = 4 * nb;                                   // (the kernel derives its workgroup count per split from XG)
+    }
     // split-K launches use the XCD-aware work map (stream_gemm.hpp): 8 * per workgroups, per = ceil(blocks / 8)
     const int xper = (d.nsplit > 1 && c->xcd_map) ? cdiv(bps * d.nsplit, 8) : 0;
     const int grid = (xper ? 8 * xper : bps * d.nsplit) + (ctrl_mode ? 2 : 0);
@@ -315,7 +338,6 @@ static int launch_stream(vbmf_ctx* c, int pass, int ctrl_mode = 0, bool epi = fa
     ca.Lg = (double)c->Lg; ca.M = (double)c->M; ca.eps = c->run_eps;
     ca.H = (int)c->H; ca.spectral = (c->o.reference_compat & VBMF_COMPAT_SPECTRAL_DELTA) ? 1 : 0;
     ca.end_flags = c->run_flags; ca.mode = ctrl_mode; ca.it_row = (int)c->ends_enqueued;
-    EpiArgs ea{};
     ea.frag_out = frag_out ? 1 : 0;
     if (epi) {
         c->sready_seq = (c->sready_seq + 1) & 0x3fffffff;
@@ -324,6 +346,7 @@ static int launch_stream(vbmf_ctx* c, int pass, int ctrl_mode = 0, bool epi = fa
         ea.spin_limit = c->epi_spin_limit;
         ea.store_fac = c->in_run ? 0 : 1;
         ea.trpart = c->trpart;
+        ea.stamp = reinterpret_cast<unsigned long long*>(c->ints + 16);
         c->ntr = 4 * bps;
         if (c->in_run) c->B32_stale = true;
         if (ctrl_mode) { ca.sready = c->ints + I_SREADY; ca.sready_val = c->sready_seq; }
@@ -339,7 +362,7 @@ static int launch_stream(vbmf_ctx* c, int pass, int ctrl_mode = 0, bool epi = fa
                                    c->stream, Y, F, out, XG, d.KS, d.steps_per_split, d.nsplit, ld, c->ints + I_STOP, ca, xper, ea);
             } else {
                 using Cfg = StreamCfg<2>;
-                hipLaunchKernelGGL((stream_gemm_kernel<MODEc, 2, Cfg::NXWc, Cfg::DYc, Cfg::DFc, Cfg::Rc, 0, 1>), dim3(grid), dim3(256), lds,
+                hipLaunchKernelGGL((stream_gemm_kernel<MODEc, 2, Cfg::NXWc, VBMF_EPI_DY, Cfg::DFc, Cfg::Rc, 0, 1>), dim3(grid), dim3(256), lds,
                                    c->stream, Y, F, out, XG, d.KS, d.steps_per_split, d.nsplit, ld, c->ints + I_STOP, ca, xper, ea);
             }
         });
@@ -424,28 +447,30 @@ static int launch_post_frag(vbmf_ctx* c) {
     HIPCHK(c, hipGetLastError());
     return VBMF_OK;
 }
-static int launch_post_gram(vbmf_ctx* c, int which, const float* In, int nslab, bool frag = false) {
+// post + Gram (+ delta-Gram, tr(B'YA)) of ONE fragment-major product (NH <= 2): post_gram2_kernel
+static int launch_post_gram(vbmf_ctx* c, int which, const float* In) {
     const Dims& d = which == 0 ? c->d1 : c->d2;
-    const long long ld = (long long)d.XT * 32;
-    const long long slabStride = (long long)c->Hp * ld;
     const float* S = which == 0 ? c->SA32 : c->SB32;
     float* Fac = which == 0 ? c->A32 : c->B32[c->bcur ^ 1];
-    const float* Prev = which == 0 ? nullptr : c->B32[c->bcur];
     uint4* Ft = which == 0 ? c->FA : c->FB;
     const unsigned char* mk = (which == 0 && c->has_mask) ? c->mask : nullptr;
     const int hstart = (int)(c->H - c->H1);
-    const int grid = std::min(256, (d.XT + 3) / 4);
+    const int grid = std::min(c->gslab_cap, (d.XT + 3) / 4);
     const int* stop = c->ints + I_STOP;
     double* trp = (which == 1 && !c->diagvar) ? c->trpart : nullptr;
+    // inside the run loops the fp32 copy of B is not written per sweep: the operand tiles carry the factor (rebuilt once at the end)
+    const int store_fac = (which == 1 && c->in_run) ? 0 : 1;
+    if (!store_fac) c->B32_stale = true;
     DISPATCH_MODE(c->mode, {
-        if (frag) {
-            if (c->NH == 1) hipLaunchKernelGGL((post_gram_kernel<MODEc, 1, true>), dim3(grid), dim3(256), 0, c->stream, In, ld, nslab, slabStride, S, Fac, Prev, Ft, mk, hstart, d.XT, c->gslab, stop, trp);
-            else hipLaunchKernelGGL((post_gram_kernel<MODEc, 2, true>), dim3(grid), dim3(256), 0, c->stream, In, ld, nslab, slabStride, S, Fac, Prev, Ft, mk, hstart, d.XT, c->gslab, stop, trp);
+        if (which == 0) {
+            if (c->NH == 1) hipLaunchKernelGGL((post_gram2_kernel<MODEc, 1, false>), dim3(grid), dim3(256), 0, c->stream, In, S, Fac, Ft, mk, hstart, d.XT, c->gslab, stop, trp, store_fac);
+            else hipLaunchKernelGGL((post_gram2_kernel<MODEc, 2, false>), dim3(grid), dim3(256), 0, c->stream, In, S, Fac, Ft, mk, hstart, d.XT, c->gslab, stop, trp, store_fac);
         } else {
-            if (c->NH == 1) hipLaunchKernelGGL((post_gram_kernel<MODEc, 1>), dim3(grid), dim3(256), 0, c->stream, In, ld, nslab, slabStride, S, Fac, Prev, Ft, mk, hstart, d.XT, c->gslab, stop, trp);
-            else hipLaunchKernelGGL((post_gram_kernel<MODEc, 2>), dim3(grid), dim3(256), 0, c->stream, In, ld, nslab, slabStride, S, Fac, Prev, Ft, mk, hstart, d.XT, c->gslab, stop, trp);
+            if (c->NH == 1) hipLaunchKernelGGL((post_gram2_kernel<MODEc, 1, true>), dim3(grid), dim3(256), 0, c->stream, In, S, Fac, Ft, mk, hstart, d.XT, c->gslab, stop, trp, store_fac);
+            else hipLaunchKernelGGL((post_gram2_kernel<MODEc, 2, true>), dim3(grid), dim3(256), 0, c->stream, In, S, Fac, Ft, mk, hstart, d.XT, c->gslab, stop, trp, store_fac);
         }
     });
+    HIPCHK(c, hipGetLastError());
     return launch_pair_reduce(c, which, grid, trp ? 4 * grid : 0);
 }
 
@@ -693,11 +718,11 @@ static int do_update_A(vbmf_ctx* c, bool reuse_P = false) {
                 TRY(allreduce_sum(c, c->P, c->Pred, (size_t)n, false));
         }
         TRY(side_join(c));
-        if (fused_gram(c)) TRY(launch_post_gram(c, 0, c->Pred, 1, c->P_frag));
+        if (fused_gram(c)) TRY(launch_post_gram(c, 0, c->Pred));
         else TRY(launch_post(c, 0, c->Pred, 1));
     } else {
         TRY(side_join(c));
-        if (fused_gram(c)) TRY(launch_post_gram(c, 0, c->P, 1, c->P_frag));
+        if (fused_gram(c)) TRY(launch_post_gram(c, 0, c->P));
         else TRY(launch_post(c, 0, c->P, 1));
     }
     if (!fused_gram(c)) TRY(launch_gram(c, 0, c->A32, nullptr, true));
@@ -738,8 +763,9 @@ static int do_update_B(vbmf_ctx* c) {
         return VBMF_OK;
     }
     // H >= 128, un-split pass: the product travels fragment-major (16-byte accesses on both sides)
-    // H <= 64 with a split pass (short row shards): fragment-major slabs, folded element-wise, read by post_gram
-    const bool fragq = (!fused_gram(c) && c->d2.nsplit == 1) || (fused_gram(c) && c->d2.nsplit > 1);
+    // H <= 64 without the register epilogue (split pass on short row shards, narrow geometry): always fragment-major -- slabs
+    // are folded element-wise and post_gram2_kernel reads the layout
+    const bool fragq = fused_gram(c) || c->d2.nsplit == 1;
     if (fused_ctrl(c)) {
         TRY(launch_stream(c, 1, CTRL_COV_B | CTRL_EIG_BOLD, false, nullptr, fragq));
     } else if (side_overlap(c)) {
@@ -754,7 +780,7 @@ static int do_update_B(vbmf_ctx* c) {
     TRY(fold_Q_slabs(c));
     TRY(side_join(c));
     if (fused_gram(c)) {
-        TRY(launch_post_gram(c, 1, c->Q, 1, fragq));
+        TRY(launch_post_gram(c, 1, c->Q));
     } else {
         if (fragq) TRY(launch_post_frag(c));
         else TRY(launch_post(c, 1, c->Q, 1));
@@ -798,6 +824,20 @@ static int device_err_status(vbmf_ctx* c, int e) {
         FAIL(c, VBMF_ERR_SYNC, "in-launch hand-off timed out: the Y*A pass's register epilogue gave up waiting for the SigmaB "
                                "table of its own launch (bounded spin); this sweep's state is not valid");
     FAIL(c, VBMF_ERR_NUMERIC, "non-positive or non-finite pivot while inverting an H x H posterior precision");
+}
+
+// the fp32 row-major BHat from its operand tiles, after run loops that skipped the per-sweep fp32 store
+static int rebuild_B32_if_stale(vbmf_ctx* c) {
+    if (!c->B32_stale) return VBMF_OK;
+    const int grid = (c->d2.XT + 3) / 4;
+    DISPATCH_MODE(c->mode, {
+        if (c->NH == 1) hipLaunchKernelGGL((untile_factor_kernel<MODEc, 1>), dim3(grid), dim3(256), 0, c->stream, c->FB, c->B32[c->bcur], c->d2.XT);
+        else hipLaunchKernelGGL((untile_factor_kernel<MODEc, 2>), dim3(grid), dim3(256), 0, c->stream, c->FB, c->B32[c->bcur], c->d2.XT);
+    });
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->B32_stale = false;
+    return VBMF_OK;
 }
 
 static int check_device_err(vbmf_ctx* c) {
@@ -910,6 +950,7 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
     if (c->Hp > 128 && c->Hp < 256) c->Hp = 256;
     c->NH = c->Hp / 32;
     if (const char* e = getenv("VBMF_XCD_MAP")) c->xcd_map = atoi(e) != 0;      // A/B switch for the tuning record
+    if (const char* e = getenv("VBMF_EPI_BALANCE")) c->epi_balance = atoi(e) != 0;
     // H >= 128: one Gram workgroup per chunk (gram_tiles_kernel): enough chunks to fill the chip, few enough that the
     // fp64 reduction over the chunks' dense H x H slabs stays small (it was 412 us at 1M rows with 16-tile chunks)
     c->tiles_per_chunk = c->NH >= 4 ? (int)std::max<int64_t>(16, cdiv(cdiv(std::max(L, M), 32), 384)) : 32;
@@ -934,7 +975,7 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
         c->narrow = c->NH <= 2 && (ev ? atoi(ev) != 0 : groups <= 2);
     }
     plan_pass(c->d1, M, L, c->kstep, c->NH, c->Hp, ybytes, c->o.pass1_splits, c->narrow);
-    plan_pass(c->d2, L, M, c->kstep, c->NH, c->Hp, ybytes, 0, c->narrow);
+    plan_pass(c->d2, L, M, c->kstep, c->NH, c->Hp, ybytes, 0, c->narrow, (c->NH == 2 && !c->narrow) ? VBMF_EPI_DY : 0);
     c->Mp = (int64_t)c->d1.XT * 32;
     c->Lp = (int64_t)c->d2.XT * 32;
     // the post kernel writes operand tiles for every 32-row tile of the factor: the consumer's KS must cover them
@@ -983,7 +1024,7 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
     c->trpart_cap = 4 * std::max(c->gslab_cap, (c->d2.XT + 3) / 4 + 1);
     ALLOC(c->trpart, (size_t)c->trpart_cap * 8);
     ALLOC(c->ypart, (size_t)16384 * 8);
-    ALLOC(c->ints, 16 * sizeof(int));
+    ALLOC(c->ints, 32 * sizeof(int));          // [0..7] flags, [8..15] control-chain stamps, [16..23] epilogue stamps
     ALLOC(c->mask, (size_t)c->Mp);
     if (c->sparse) {
         ALLOC(c->dS32, (size_t)c->Mp * c->Hp * 4);
@@ -1483,15 +1524,7 @@ int vbmf_run(vbmf_ctx* c, int64_t niter, double eps, int est_covs, int est_var, 
     if (rc == VBMF_OK) {
         const int done = c->ints_host[I_ITERS];
         c->bcur = bstart ^ (done & 1);                    // sweeps after `stop` were no-ops on the device
-        if (c->B32_stale) {                               // the fp32 factor from the tiles the last executed sweep wrote
-            const int grid = (c->d2.XT + 3) / 4;
-            DISPATCH_MODE(c->mode, {
-                if (c->NH == 1) hipLaunchKernelGGL((untile_factor_kernel<MODEc, 1>), dim3(grid), dim3(256), 0, c->stream, c->FB, c->B32[c->bcur], c->d2.XT);
-                else hipLaunchKernelGGL((untile_factor_kernel<MODEc, 2>), dim3(grid), dim3(256), 0, c->stream, c->FB, c->B32[c->bcur], c->d2.XT);
-            });
-            if (hipStreamSynchronize(c->stream) != hipSuccess) { c->err = "factor rebuild failed"; rc = VBMF_ERR_HIP; }
-            c->B32_stale = false;
-        }
+        rc = rebuild_B32_if_stale(c);                     // the fp32 factor from the tiles the last executed sweep wrote
         if (iters_done) *iters_done = done;
         if (d_last && done > 0) *d_last = c->scal_host[S_D];
         if (trace && done > 0) {
@@ -1628,7 +1661,7 @@ int vbmf_debug_peek(vbmf_ctx* c, int what, uint32_t* out, int64_t nwords, int64_
         return VBMF_OK;
     }
     if (what == VBMF_PEEK_CHAIN) {
-        if (nwords > 8) FAIL(c, VBMF_ERR_INVALID, "vbmf_debug_peek: the chain stamps are 8 words");
+        if (nwords > 16) FAIL(c, VBMF_ERR_INVALID, "vbmf_debug_peek: the chain stamps are 16 words");
         HIPCHK(c, hipMemcpy(out, c->ints + 8, (size_t)nwords * 4, hipMemcpyDeviceToHost));
         return VBMF_OK;
     }
@@ -1810,12 +1843,14 @@ static int do_sparse_update_B(vbmf_ctx* c) {
     } else {
         TRY(launch_sparse_cov_b(c));
     }
-    const bool fragq = !fused_gram(c) && c->d2.nsplit == 1 && !c->diagvar;   // (the row-noise update reads the plain product)
+    // fragment-major product: H <= 64 always (folded element-wise when split), H >= 128 when un-split; the row-noise update
+    // reads the plain product
+    const bool fragq = !c->diagvar && (fused_gram(c) || c->d2.nsplit == 1);
     TRY(launch_stream(c, 1, 0, false, nullptr, fragq));
     TRY(fold_Q_slabs(c));
     TRY(side_join(c));
     if (fused_gram(c) && !c->diagvar) {
-        TRY(launch_post_gram(c, 1, c->Q, 1));
+        TRY(launch_post_gram(c, 1, c->Q));
     } else {
         if (fragq) TRY(launch_post_frag(c));
         else TRY(launch_post(c, 1, c->Q, 1));
@@ -1962,6 +1997,7 @@ int vbmf_sparse_set_state(vbmf_ctx* c, const double* ATVecHat, const double* dia
     c->gA_valid = c->gB_valid = c->P_valid = c->tr_valid = false;
     c->Q_valid = false;
     c->have_noise = false;
+    c->B32_stale = false;
     c->haveState = true;
     return VBMF_OK;
 }
@@ -2106,9 +2142,10 @@ static int sparse_run_impl(vbmf_ctx* c, int64_t niter, double eps, int est_cb, i
     if (rc == VBMF_OK) {
         const int done = c->ints_host[I_ITERS];
         c->bcur = bstart ^ (done & 1);
+        rc = rebuild_B32_if_stale(c);
         if (iters_done) *iters_done = done;
         if (d_last && done > 0) *d_last = c->scal_host[S_D];
-        if (trace && done > 0 && hipMemcpy(trace, trace_dev, (size_t)done * 4 * 8, hipMemcpyDeviceToHost) != hipSuccess) { c->err = "trace copy failed"; rc = VBMF_ERR_HIP; }
+        if (rc == VBMF_OK && trace && done > 0 && hipMemcpy(trace, trace_dev, (size_t)done * 4 * 8, hipMemcpyDeviceToHost) != hipSuccess) { c->err = "trace copy failed"; rc = VBMF_ERR_HIP; }
         if (c->ints_host[I_ERR]) { c->err = "non-positive or non-finite pivot while inverting the posterior precision of B"; rc = VBMF_ERR_NUMERIC; }
     }
     int zero4[4] = {0, 0, 0, 0};
