@@ -253,4 +253,6 @@ def test_trial_lower_bound_trimmed(pkg):
     for trim in (1e-1, 0.7):
         want, got = O.lowerBoundTrimmed(Yf, po, trim), pkg.lowerBoundTrimmed(Yf, _to_pkg(pkg, po), trim)
         report(f"trial lowerBoundTrimmed trim={trim:g}: gpu {got:.6f} oracle {want:.6f}")
-        assert abs(got - want) <= 2e-5 * abs(want) + 1e-3, (trim, got, want)      # the tolerance of the untrimmed bound above
+        # the device's bound carries the same absolute error with and without the mask (fp32 storage of beta / CA): the
+        # untrimmed bound's tolerance, 2e-5 of ITS magnitude
+        assert abs(got - want) <= 2e-5 * abs(O.lowerBound_trial(Yf, po)) + 1e-3, (trim, got, want)

@@ -515,8 +515,8 @@ def _spull(c, p, diag_var=False):
 
 
 def _check_full_cov(full_cov, diag_var, H):
-    if full_cov and (diag_var or H > 64):
-        raise NotImplementedError("full_cov=true is built for diag_var=false and H <= 64")
+    if full_cov and (diag_var or H > 128):
+        raise NotImplementedError("full_cov=true is built for diag_var=false and H <= 128")
 
 
 def _sone(Y, p, which, diag_var=False, full_cov=False):

@@ -24,11 +24,31 @@ def hipcc_path():
     raise RuntimeError("hipcc not found (ROCm toolchain required to build libvbmf_hip.so)")
 
 
+STAMP = OUT + ".srchash"
+
+
+def _flags():
+    return ["--offload-arch=gfx950", "-O3", "-std=c++17"] + os.environ.get("VBMF_HIPCC_FLAGS", "").split()
+
+
+def source_hash():
+    """SHA-256 over every source the library is built from (csrc/*, include/vbmf_hip.h) and the compile flags."""
+    import hashlib
+    h = hashlib.sha256(" ".join(_flags()).encode())
+    for d in DEPS:
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def up_to_date():
-    if not os.path.exists(OUT):
+    """The in-tree library was built from exactly these sources (content hash recorded beside it at build time -- not file
+    times: a .so that travelled with the tree but belongs to other sources is rebuilt)."""
+    if not (os.path.exists(OUT) and os.path.exists(STAMP)):
         return False
-    t = os.path.getmtime(OUT)
-    return all(os.path.getmtime(d) <= t for d in DEPS)
+    with open(STAMP) as f:
+        return f.read().strip() == source_hash()
 
 
 def build(force=False, verbose=False, out=OUT):
@@ -48,6 +68,9 @@ def build(force=False, verbose=False, out=OUT):
     if verbose:
         sys.stderr.write(r.stderr)
     os.replace(out + ".tmp", out)
+    if out == OUT:
+        with open(STAMP, "w") as f:
+            f.write(source_hash() + "\n")
     return out
 
 

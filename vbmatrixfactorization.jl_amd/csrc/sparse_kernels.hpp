@@ -73,7 +73,9 @@ __global__ __launch_bounds__(256) void sparse_update_a_kernel(const float* __res
 // Two columns per round and workgroup (gj_tiled_n<R, T, 2>, one barrier per pivot for both).  Measured: only +2.5 % over one
 // column per round -- with two workgroups per CU the sweep is bound by instruction issue (~70 instructions per pivot step and
 // wave), not by the LDS round trips; an fp64-MFMA rank-4 update per 16 x 16 tile is what would change that.
-template <int R, int T>
+// NB columns per round and workgroup: 2 up to H = 64; 1 for 64 < H <= 128 (R = 8: a second 128 x 128 fp64 block would not fit
+// the register file beside the running sum of the blocks).
+template <int R, int T, int NB = 2>
 __global__ __launch_bounds__(T * T) void sparse_update_a_full_kernel(const float* __restrict__ P, long long ldP,
                                                                      const float* __restrict__ CA32,
                                                                      const double* __restrict__ st, StateLayout lay,
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(T * T) void sparse_update_a_full_kernel(const float
                                                                      double* __restrict__ part, int* __restrict__ ints) {
     extern __shared__ __attribute__((aligned(16))) double lds_full[];
     if (load_stop(ints)) return;
-    constexpr int NP = T * R, NB = 2;
+    constexpr int NP = T * R;
     const int tx = threadIdx.x % T, ty = threadIdx.x / T;
     double* strip = lds_full;                      // NB * 4 * NP
     double* pivs = lds_full + NB * 4 * NP;         // NB * NP

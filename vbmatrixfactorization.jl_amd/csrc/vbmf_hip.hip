@@ -542,7 +542,7 @@ static int launch_gram(vbmf_ctx* c, int which, const float* cur, const float* pr
     double* outG = shard ? c->gtmp : c->st + (which == 0 ? c->lay.GA() : c->lay.GB());
     double* outD = which == 0 ? nullptr : (shard ? c->gtmp + n : c->st + c->lay.GD());
     double* outTr = (which == 1 && ntr > 0) ? (shard ? c->gtmp + 2 * n : c->st + c->lay.GX()) : nullptr;
-    hipLaunchKernelGGL(gram_reduce_kernel, dim3((2 * n + 255) / 256), dim3(256), 0, c->stream, c->gslab, nchunk, n,
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3((2 * n + 31) / 32), dim3(256), 0, c->stream, c->gslab, nchunk, n,
                        outG, outD, stop, c->trpart, ntr, outTr);
     HIPCHK(c, hipGetLastError());
     if (shard) {
@@ -1769,9 +1769,9 @@ static int sparse_colsum(vbmf_ctx* c) {
     return VBMF_OK;
 }
 
-template <int R, int T>
+template <int R, int T, int NB = 2>
 static void launch_full_a_t(vbmf_ctx* c) {
-    hipLaunchKernelGGL((sparse_update_a_full_kernel<R, T>), dim3(c->fblocks), dim3(T * T), (size_t)(12 * T * R) * sizeof(double), c->stream,
+    hipLaunchKernelGGL((sparse_update_a_full_kernel<R, T, NB>), dim3(c->fblocks), dim3(T * T), (size_t)(6 * NB * T * R) * sizeof(double), c->stream,
                        c->Pred, (long long)c->d1.XT * 32, c->CA32, c->st, c->lay, c->A32, c->dS32, c->has_mask ? c->mask : nullptr,
                        (int)(c->H - c->H1), (long long)c->M, (int)c->H, c->Hp, (double)c->Lg, c->fpart, c->ints);
 }
@@ -1804,7 +1804,8 @@ static int do_sparse_update_A(vbmf_ctx* c, bool reuse_P = false) {
         const int H = (int)c->H;
         if (H <= 16) launch_full_a_t<1, 16>(c);
         else if (H <= 32) launch_full_a_t<2, 16>(c);
-        else launch_full_a_t<4, 16>(c);
+        else if (H <= 64) launch_full_a_t<4, 16>(c);
+        else launch_full_a_t<8, 16, 1>(c);                 // 64 < H <= 128: one column per round and workgroup
         hipLaunchKernelGGL(full_sa_fold_kernel, dim3(cdiv(c->Hp * c->Hp, 256)), dim3(256), 0, c->stream, c->fpart, c->fblocks, c->Hp, c->st, c->lay, stop);
         HIPCHK(c, hipGetLastError());
         TRY(launch_retile(c, 0, true));
@@ -2168,10 +2169,11 @@ int vbmf_sparse_set_full_cov(vbmf_ctx* c, int on) {
     if (!c) return VBMF_ERR_INVALID;
     if (!c->sparse) FAIL(c, VBMF_ERR_INVALID, "not a sparse context");
     if (on && c->diagvar) FAIL(c, VBMF_ERR_UNSUPPORTED, "full_cov with diag_var is not built");
-    if (on && c->H > 64) FAIL(c, VBMF_ERR_UNSUPPORTED, "full_cov is built for H <= 64");
+    if (on && c->H > 128) FAIL(c, VBMF_ERR_UNSUPPORTED, "full_cov is built for H <= 128 (one H x H fp64 block per column of Y must fit a workgroup's registers)");
     HIPCHK(c, hipSetDevice(c->o.device));
     if (on && !c->fpart) {
-        c->fblocks = (int)std::max<int64_t>(1, std::min<int64_t>((c->M + 1) / 2, 1024));     // two columns per round and workgroup
+        // two columns per round and workgroup (one for H > 64)
+        c->fblocks = (int)std::max<int64_t>(1, std::min<int64_t>(c->H > 64 ? c->M : (c->M + 1) / 2, 1024));
         const size_t bytes = (size_t)c->fblocks * c->Hp * c->Hp * 8;
         HIPCHK(c, hipMalloc((void**)&c->fpart, bytes));
         HIPCHK(c, hipMemset(c->fpart, 0, bytes));
