@@ -290,7 +290,7 @@ def test_full_cov_logged_trajectory_against_the_reference_record(pkg, golden_dir
     assert abs(p.zeta - 21.72598805535064) < 2e-3 * 21.7
 
 
-@pytest.mark.parametrize("L,M,H", [(300, 170, 5), (500, 120, 40), (400, 90, 64), (400, 60, 100)])
+@pytest.mark.parametrize("L,M,H", [(300, 170, 5), (500, 120, 40), (400, 90, 64), (400, 84, 100)])
 def test_full_cov_against_the_oracle(pkg, L, M, H):
     """Larger shapes (all four register tilings of the per-column inverse: two columns per round up to H = 64, one for
     64 < H <= 128), label mask included, against the oracle's dense kron(...) restatement; then 6 sweeps of the loop."""

@@ -87,11 +87,12 @@ constexpr int TB_LD = 33;
 template <bool RHO>
 __device__ __forceinline__ float tile_dot_qb(const float (&q)[16], const f32x16& b, float* tb, int lane) {
     const int c = lane & 31, half = lane >> 5;
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int r = 0; r < 16; ++r) tb[rho(r, half) * TB_LD + c] = b[r];
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // LDS operations of one wave execute in issue order
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");      // LDS operations of one wave execute in issue order;
+                                                                         // LDS-only fences: global loads may move across them
     __builtin_amdgcn_wave_barrier();
     float s = 0.f;
 #pragma unroll
@@ -104,17 +105,44 @@ __device__ __forceinline__ void store_wave_dot(double v, double* __restrict__ sl
     if (lane == 0) *slot = v;
 }
 
+template <int MODE, int NH>
+__device__ __forceinline__ void read_factor_tiles(const uint4* __restrict__ Ft, f32x16& v, int xt, int nh, int lane);
+
+// ---- delta tiles (H >= 128, bf16 factor modes) ---------------------------------------------------------------------------
+// d = old - new of one 32 x 32 block, formed element-wise where the new block is produced (the old one read from the factor's
+// operand tiles BEFORE they are overwritten) and stored as bf16 hi + lo operand fragments in the layout of a two-part tile
+// buffer: the delta-Gram (src/util.jl:27-29 needs ||B_old - B_new||) is then a plain tile Gram of that buffer -- 1 KiB wave
+// loads, no 4-byte row gathers of the previous fp32 factor (they were what the delta-Gram kernel spent its time on).
+template <int NH>
+__device__ __forceinline__ void write_delta_tiles(uint4* __restrict__ Fd, const f32x16& oldv, const f32x16& newv, int xt, int nh, int lane) {
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        float d[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d[e] = oldv[8 * s2 + e] - newv[8 * s2 + e];
+        u32x4v hi, lo;
+        split8_bf16(d, hi, lo);
+        const long long base = (long long)(2 * xt + s2) * 2;
+        Fd[((base + 0) * NH + nh) * 64 + lane] = uint4{hi[0], hi[1], hi[2], hi[3]};
+        Fd[((base + 1) * NH + nh) * 64 + lane] = uint4{lo[0], lo[1], lo[2], lo[3]};
+    }
+}
+
 // One wave per NXT consecutive 32-row tiles of the factor (NXT = 1 up to H = 64; from H = 128 on several tiles share
 // every fetch of the H x H table, which no longer fits a wave's registers: 16 accumulator tiles per wave).
 // In: [nslab][Hp][ldIn] fp32 (x fastest), S: [Hp][Hp] fp32 row-major, Fac: [XT*32][Hp] fp32 row-major.
-template <int NH> struct PostCfg { static constexpr int NXT = NH >= 8 ? 2 : 1; };    // (more tiles per wave at H = 128 are slower: 591 -> 830 us per 1M rows)
+#ifndef VBMF_POST_NXT8
+#define VBMF_POST_NXT8 2          // tuning switch (A/B on the GPU): 32-row tiles per wave of the H = 256 post kernels
+#endif
+template <int NH> struct PostCfg { static constexpr int NXT = NH >= 8 ? VBMF_POST_NXT8 : 1; };    // (more tiles per wave at H = 128 are slower: 591 -> 830 us per 1M rows)
 
 template <int MODE, int NH>
 __global__ __launch_bounds__(256) void post_kernel(const float* __restrict__ In, long long ldIn, int nslab,
                                                    long long slabStride, const float* __restrict__ S,
                                                    float* __restrict__ Fac, uint4* __restrict__ Ft,
                                                    const unsigned char* __restrict__ mask, int hmask_start, int XT,
-                                                   const int* __restrict__ stop, double* __restrict__ trpart = nullptr) {
+                                                   const int* __restrict__ stop, double* __restrict__ trpart = nullptr,
+                                                   uint4* __restrict__ Fd = nullptr, int store_fac = 1) {
     constexpr int Hp = NH * 32;
     constexpr int NXT = PostCfg<NH>::NXT;
     __shared__ float tbuf[4][32 * TB_LD];
@@ -174,9 +202,16 @@ __global__ __launch_bounds__(256) void post_kernel(const float* __restrict__ In,
                 for (int r = 0; r < 16; ++r)
                     if (mask[x0 + rho(r, half)]) acc[i][h][r] = 0.f;
             }
+            // Fd (B side, bf16 factor modes): old - new of this block as delta tiles; the old block comes from the operand
+            // tiles this wave is about to overwrite.  store_fac = 0 (inside the run loops): no fp32 copy per sweep.
+            f32x16 oldv;
+            if (Fd != nullptr) read_factor_tiles<MODE, NH>(Ft, oldv, xt, h, lane);
             write_factor_tiles<MODE, NH>(Ft, acc[i][h], xt, h, lane);
+            if (Fd != nullptr) write_delta_tiles<NH>(Fd, oldv, acc[i][h], xt, h, lane);
+            if (store_fac) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) Fac[(x0 + rho(r, half)) * Hp + hcol] = acc[i][h][r];
+                for (int r = 0; r < 16; ++r) Fac[(x0 + rho(r, half)) * Hp + hcol] = acc[i][h][r];
+            }
         }
     }
     if (trpart) {                                            // tr(B'YA): the product rows again (L2-hot), block by block
@@ -210,7 +245,9 @@ template <int MODE, int NH>
 __global__ __launch_bounds__(256) void post_frag_kernel(const float4* __restrict__ In4, const float* __restrict__ S,
                                                         float* __restrict__ Fac, uint4* __restrict__ Ft,
                                                         const unsigned char* __restrict__ mask, int hmask_start, int XT,
-                                                        const int* __restrict__ stop, double* __restrict__ trpart = nullptr) {
+                                                        const int* __restrict__ stop, double* __restrict__ trpart = nullptr,
+                                                        uint4* __restrict__ Fd = nullptr, int store_fac = 1,
+                                                        const uint4* __restrict__ Sf = nullptr) {
     constexpr int Hp = NH * 32;
     constexpr int NXT = PostCfg<NH>::NXT;
     __shared__ float tbuf[4][32 * TB_LD];
@@ -268,11 +305,18 @@ __global__ __launch_bounds__(256) void post_frag_kernel(const float4* __restrict
                 for (int i = 0; i < NXT; ++i) split8(&a[i][8 * s2], ah[i], al[i]);
 #pragma unroll
                 for (int h = 0; h < NH; ++h) {
-                    float b[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) b[e] = S[(long long)(hin * 32 + rho(8 * s2 + e, half)) * Hp + h * 32 + c];
                     u32x4v bh, bl;
-                    split8(b, bh, bl);
+                    if (Sf != nullptr) {                     // the table's fragments, split once per sweep (split_table_kernel)
+                        const int combo = (hin * 2 + s2) * NH + h;
+                        const uint4 xh = Sf[(combo * 2 + 0) * 64 + lane], xl = Sf[(combo * 2 + 1) * 64 + lane];
+                        bh = u32x4v{xh.x, xh.y, xh.z, xh.w};
+                        bl = u32x4v{xl.x, xl.y, xl.z, xl.w};
+                    } else {
+                        float b[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) b[e] = S[(long long)(hin * 32 + rho(8 * s2 + e, half)) * Hp + h * 32 + c];
+                        split8(b, bh, bl);
+                    }
 #pragma unroll
                     for (int i = 0; i < NXT; ++i) {
                         acc[i][h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bh), acc[i][h], 0, 0, 0);
@@ -296,9 +340,16 @@ __global__ __launch_bounds__(256) void post_frag_kernel(const float4* __restrict
                 for (int r = 0; r < 16; ++r)
                     if (mask[x0 + rho(r, half)]) acc[i][h][r] = 0.f;
             }
+            // Fd (B side, bf16 factor modes): old - new of this block as delta tiles; the old block comes from the operand
+            // tiles this wave is about to overwrite.  store_fac = 0 (inside the run loops): no fp32 copy per sweep.
+            f32x16 oldv;
+            if (Fd != nullptr) read_factor_tiles<MODE, NH>(Ft, oldv, xt, h, lane);
             write_factor_tiles<MODE, NH>(Ft, acc[i][h], xt, h, lane);
+            if (Fd != nullptr) write_delta_tiles<NH>(Fd, oldv, acc[i][h], xt, h, lane);
+            if (store_fac) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) Fac[(x0 + rho(r, half)) * Hp + hcol] = acc[i][h][r];
+                for (int r = 0; r < 16; ++r) Fac[(x0 + rho(r, half)) * Hp + hcol] = acc[i][h][r];
+            }
         }
     }
     if (trpart) {                                            // tr(B'YA): the product fragments again (L2-hot), block by block
@@ -509,6 +560,27 @@ __device__ __forceinline__ void load_sigma_table(float* stab, const float* __res
     constexpr int Hp = NH * 32;
     for (int i = threadIdx.x; i < Hp * Hp / 4; i += 256)
         reinterpret_cast<float4*>(stab)[i] = reinterpret_cast<const float4*>(S)[i];
+}
+
+// The Sigma / sigma2 table as pre-split bf16 hi / lo MFMA fragments [(hin, s2, h)][hi | lo][lane] for post_frag_kernel's
+// three-term product: split ONCE per sweep here instead of by every wave for every tile pair (8 four-byte loads and two
+// splits per fragment: 1024 scattered loads per wave at H = 256, what the kernel spent most of its time on).
+template <int NH>
+__global__ __launch_bounds__(256) void split_table_kernel(const float* __restrict__ S, uint4* __restrict__ Sf,
+                                                          const int* __restrict__ stop) {
+    constexpr int Hp = NH * 32;
+    if (stop && *stop) return;
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= NH * 2 * NH * 64) return;
+    const int ln = w & 63, combo = w >> 6;
+    const int h = combo % NH, s2 = (combo / NH) & 1, hin = combo / (2 * NH);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = S[(long long)(hin * 32 + rho(8 * s2 + e, ln >> 5)) * Hp + h * 32 + (ln & 31)];
+    u32x4v hi, lo;
+    split8_bf16(v, hi, lo);
+    Sf[(combo * 2 + 0) * 64 + ln] = uint4{hi[0], hi[1], hi[2], hi[3]};
+    Sf[(combo * 2 + 1) * 64 + ln] = uint4{lo[0], lo[1], lo[2], lo[3]};
 }
 
 // ---- fused post + Gram (NH <= 2), second form: the tile body of the register epilogue as its own kernel ------------------
@@ -733,10 +805,12 @@ __global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ Cur
 // One workgroup per chunk of tiles; wave w owns the upper-triangular tile pairs p = w (mod 4); slab format of gram_kernel.
 // WHAT = 0: the Gram only; 1: the delta-Gram only (two launches at H = 256: 9 pair tiles per wave and matrix, and both
 // matrices' accumulators together with the fragments would spill).
+// out_which (WHAT = 0): the slab half the result goes to -- 0 for a factor's own Gram, 1 when `Ft` is a DELTA tile buffer
+// (write_delta_tiles) and the result is the delta-Gram.
 template <int NH, int NPART, int WHAT>
 __global__ __launch_bounds__(256) void gram_tiles_kernel(const uint4* __restrict__ Ft, const float* __restrict__ Prev,
                                                          float* __restrict__ slabs, int XT, int tiles_per_chunk,
-                                                         const int* __restrict__ stop) {
+                                                         const int* __restrict__ stop, int out_which = WHAT) {
     constexpr int Hp = NH * 32;
     constexpr int NPAIR = NH * (NH + 1) / 2;
     constexpr int PW = (NPAIR + 3) / 4;
@@ -817,7 +891,7 @@ __global__ __launch_bounds__(256) void gram_tiles_kernel(const uint4* __restrict
         }
     }
     // accumulator (lane (half, c), register r) = element (row rho(r, half) of tile h1, column c of tile h2); both triangles
-    float* o = slabs + ((long long)chunk * 2 + WHAT) * Hp * Hp;
+    float* o = slabs + ((long long)chunk * 2 + out_which) * Hp * Hp;
     int p = 0;
 #pragma unroll
     for (int h1 = 0; h1 < NH; ++h1)

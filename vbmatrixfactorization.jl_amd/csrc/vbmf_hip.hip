@@ -53,6 +53,9 @@ struct vbmf_ctx {
     int64_t Mp = 0, Lp = 0;
     uint4 *Y1 = nullptr, *Y2 = nullptr, *FA = nullptr, *FB = nullptr;   // FA/FB point PAST PIPE_D leading zero k-steps
     uint4 *FA_alloc = nullptr, *FB_alloc = nullptr;
+    uint4* SBf = nullptr;            // SigmaB table pre-split into bf16 hi / lo MFMA fragments (H >= 128, bf16 factor modes)
+    uint4* FD = nullptr;             // delta tiles of B (H >= 128, bf16 factor modes): old - new as bf16 hi + lo operand fragments
+    bool fd_valid = false;           // ... written by the post kernel of the B update just enqueued
     size_t nY1 = 0, nY2 = 0, nFA = 0, nFB = 0;
     float *P = nullptr, *Q = nullptr, *Pred = nullptr;
     float *A32 = nullptr, *B32[2] = {nullptr, nullptr};
@@ -416,13 +419,18 @@ static int launch_post(vbmf_ctx* c, int which, const float* In, int nslab) {
     uint4* Ft = which == 0 ? c->FA : c->FB;
     const unsigned char* mk = (which == 0 && c->has_mask) ? c->mask : nullptr;
     const int hstart = (int)(c->H - c->H1);
-    const int nxt = c->NH >= 8 ? 2 : 1;                          // = PostCfg<NH>::NXT
+    const int nxt = c->NH >= 8 ? VBMF_POST_NXT8 : 1;                          // = PostCfg<NH>::NXT
     const int grid = (cdiv(d.XT, nxt) + 3) / 4;
     double* trp = (which == 1 && !c->diagvar && 4 * grid <= c->trpart_cap) ? c->trpart : nullptr;   // (diag_var rescales the rows afterwards)
     c->ntr = trp ? 4 * grid : 0;
+    // B side at H >= 128 (bf16 factor modes): delta tiles for the delta-Gram; inside the run loops no fp32 copy of B per sweep
+    uint4* fd = (which == 1 && c->NH >= 4) ? c->FD : nullptr;
+    const int store_fac = (fd != nullptr && c->in_run) ? 0 : 1;
+    if (which == 1) c->fd_valid = fd != nullptr;
+    if (!store_fac) c->B32_stale = true;
     DISPATCH_MODE(c->mode, DISPATCH_NH(c->NH, {
         hipLaunchKernelGGL((post_kernel<MODEc, NHc>), dim3(grid), dim3(256), 0, c->stream, In, ld, nslab, slabStride, S,
-                           Fac, Ft, mk, hstart, d.XT, c->ints + I_STOP, trp);
+                           Fac, Ft, mk, hstart, d.XT, c->ints + I_STOP, trp, fd, store_fac);
     }));
     HIPCHK(c, hipGetLastError());
     return VBMF_OK;
@@ -436,13 +444,22 @@ static int launch_pair_reduce(vbmf_ctx* c, int which, int nslab, int ntr = 0);
 // B from a fragment-major product (H >= 128, un-split Y*A pass)
 static int launch_post_frag(vbmf_ctx* c) {
     const Dims& d = c->d2;
-    const int nxt = c->NH >= 8 ? 2 : 1;                          // = PostCfg<NH>::NXT
+    const int nxt = c->NH >= 8 ? VBMF_POST_NXT8 : 1;                          // = PostCfg<NH>::NXT
     const int grid = (cdiv(d.XT, nxt) + 3) / 4;
     double* trp = (!c->diagvar && 4 * grid <= c->trpart_cap) ? c->trpart : nullptr;
     c->ntr = trp ? 4 * grid : 0;
+    uint4* fd = c->FD;
+    const int store_fac = (fd != nullptr && c->in_run) ? 0 : 1;
+    c->fd_valid = fd != nullptr;
+    if (!store_fac) c->B32_stale = true;
+    if (c->SBf != nullptr) {
+        const int nthr = c->NH * 2 * c->NH * 64;
+        if (c->NH == 4) hipLaunchKernelGGL((split_table_kernel<4>), dim3((nthr + 255) / 256), dim3(256), 0, c->stream, c->SB32, c->SBf, c->ints + I_STOP);
+        else hipLaunchKernelGGL((split_table_kernel<8>), dim3((nthr + 255) / 256), dim3(256), 0, c->stream, c->SB32, c->SBf, c->ints + I_STOP);
+    }
     DISPATCH_MODE(c->mode, {
-        if (c->NH == 4) hipLaunchKernelGGL((post_frag_kernel<MODEc, 4>), dim3(grid), dim3(256), 0, c->stream, (const float4*)c->Q, c->SB32, c->B32[c->bcur ^ 1], c->FB, (const unsigned char*)nullptr, 0, d.XT, c->ints + I_STOP, trp);
-        else hipLaunchKernelGGL((post_frag_kernel<MODEc, 8>), dim3(grid), dim3(256), 0, c->stream, (const float4*)c->Q, c->SB32, c->B32[c->bcur ^ 1], c->FB, (const unsigned char*)nullptr, 0, d.XT, c->ints + I_STOP, trp);
+        if (c->NH == 4) hipLaunchKernelGGL((post_frag_kernel<MODEc, 4>), dim3(grid), dim3(256), 0, c->stream, (const float4*)c->Q, c->SB32, c->B32[c->bcur ^ 1], c->FB, (const unsigned char*)nullptr, 0, d.XT, c->ints + I_STOP, trp, fd, store_fac, (const uint4*)c->SBf);
+        else hipLaunchKernelGGL((post_frag_kernel<MODEc, 8>), dim3(grid), dim3(256), 0, c->stream, (const float4*)c->Q, c->SB32, c->B32[c->bcur ^ 1], c->FB, (const unsigned char*)nullptr, 0, d.XT, c->ints + I_STOP, trp, fd, store_fac, (const uint4*)c->SBf);
     });
     HIPCHK(c, hipGetLastError());
     return VBMF_OK;
@@ -520,13 +537,19 @@ static int launch_gram(vbmf_ctx* c, int which, const float* cur, const float* pr
     const bool from_tiles = c->NH >= 4 && c->mode != MODE_F32;
     if (from_tiles) {
         const uint4* Ft = which == 0 ? c->FA : c->FB;
+        // delta-Gram: a plain tile Gram of the delta tiles the post kernel left (two parts: hi + lo) -- or, without them
+        // (f32-free callers that bring their own previous fp32 factor), from `prev` with row gathers
+        const bool from_fd = which == 1 && prev != nullptr && c->fd_valid && c->FD != nullptr;
 #define GRAM_TILES(NHc_, NPc_)                                                                                               \
     do {                                                                                                                         \
         hipLaunchKernelGGL((gram_tiles_kernel<NHc_, NPc_, 0>), dim3(nchunk), dim3(256), 0, c->stream, Ft, prev, c->gslab, d.XT,   \
-                           c->tiles_per_chunk, stop);                                                                            \
-        if (prev != nullptr)                                                                                                     \
+                           c->tiles_per_chunk, stop, 0);                                                                         \
+        if (from_fd)                                                                                                             \
+            hipLaunchKernelGGL((gram_tiles_kernel<NHc_, 2, 0>), dim3(nchunk), dim3(256), 0, c->stream, (const uint4*)c->FD, prev,  \
+                               c->gslab, d.XT, c->tiles_per_chunk, stop, 1);                                                     \
+        else if (prev != nullptr)                                                                                                \
             hipLaunchKernelGGL((gram_tiles_kernel<NHc_, NPc_, 1>), dim3(nchunk), dim3(256), 0, c->stream, Ft, prev, c->gslab,      \
-                               d.XT, c->tiles_per_chunk, stop);                                                                  \
+                               d.XT, c->tiles_per_chunk, stop, 1);                                                               \
     } while (0)
         if (c->NH == 4) { if (c->npart == 2) GRAM_TILES(4, 2); else GRAM_TILES(4, 1); }
         else { if (c->npart == 2) GRAM_TILES(8, 2); else GRAM_TILES(8, 1); }
@@ -830,10 +853,9 @@ static int device_err_status(vbmf_ctx* c, int e) {
 static int rebuild_B32_if_stale(vbmf_ctx* c) {
     if (!c->B32_stale) return VBMF_OK;
     const int grid = (c->d2.XT + 3) / 4;
-    DISPATCH_MODE(c->mode, {
-        if (c->NH == 1) hipLaunchKernelGGL((untile_factor_kernel<MODEc, 1>), dim3(grid), dim3(256), 0, c->stream, c->FB, c->B32[c->bcur], c->d2.XT);
-        else hipLaunchKernelGGL((untile_factor_kernel<MODEc, 2>), dim3(grid), dim3(256), 0, c->stream, c->FB, c->B32[c->bcur], c->d2.XT);
-    });
+    DISPATCH_MODE(c->mode, DISPATCH_NH(c->NH, {
+        hipLaunchKernelGGL((untile_factor_kernel<MODEc, NHc>), dim3(grid), dim3(256), 0, c->stream, c->FB, c->B32[c->bcur], c->d2.XT);
+    }));
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->B32_stale = false;
@@ -887,7 +909,7 @@ int vbmf_destroy(vbmf_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     prof_harvest(c);
     if (c->comm) ncclCommDestroy(c->comm);
-    void* bufs[] = {c->Y1, c->Y2, c->FA_alloc, c->FB_alloc, c->P, c->Q, c->Pred, c->A32, c->B32[0], c->B32[1], c->SA32,
+    void* bufs[] = {c->Y1, c->Y2, c->FA_alloc, c->FB_alloc, c->FD, c->SBf, c->P, c->Q, c->Pred, c->A32, c->B32[0], c->B32[1], c->SA32,
                     c->SB32, c->gslab, c->st, c->gtmp, c->ypart, c->trpart, c->ints, c->mask, c->dS32, c->CA32, c->beta32, c->vtab,
                     c->sigv, c->zetav, c->yrow, c->hpart, c->vsq, c->sig32, c->G32, c->FBs_alloc, c->gpart, c->fpart};
     for (void* b : bufs) if (b) hipFree(b);
@@ -1000,6 +1022,9 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
     ALLOC(c->Y1, c->nY1 * 16);
     ALLOC(c->Y2, c->nY2 * 16);
     ALLOC(c->FB_alloc, (c->nFB + flead) * 16);
+    if (c->NH >= 4 && c->mode != MODE_F32) ALLOC(c->SBf, (size_t)c->NH * 2 * c->NH * 2 * 64 * 16);
+    if (c->NH >= 4 && c->mode != MODE_F32 && !c->diagvar)
+        ALLOC(c->FD, ((size_t)c->d1.KS + PIPE_D) * 2 * c->NH * 64 * 16);
     ALLOC(c->FA_alloc, (c->nFA + flead) * 16);
     c->FB = c->FB_alloc + flead;
     c->FA = c->FA_alloc + flead;
