@@ -15,8 +15,12 @@ partial of Y'B and the packed Grams all-reduced with RCCL inside the library, on
 
 Prints ONE JSON line on rank 0.  `roofline` is for the streaming-contraction kernel (both passes of a
 sweep are launches of it): algorithmic bytes per launch / average launch duration, measured with HIP
-events recorded on the library's own stream during the timed region.  `cpu_baseline` times the fp64
-oracle in the reference's operation order (OpenBLAS, all host cores) on a bounded row-sample.
+events recorded on the library's own stream during the timed region.  `roofline.traffic` is the
+PMC-measured HBM traffic per launch (committed figure, `traffic_source` names the profile file it comes from);
+`roofline.sweep_frac` prices the WHOLE sweep (algorithmic bytes of both passes / ms_per_step) against the same peak.
+`cpu_baseline` times the fp64 oracle in the reference's operation order (OpenBLAS, all host cores) on ALL rows of the
+workload for `--cpu-sweeps` sweeps (`--cpu-rows N` bounds it to a row sample instead).  `--settle-seconds` runs untimed
+pass launches (state not advanced) before the warm-up so the clocks are settled when the timed region starts.
 `control_chain_us`: last durations of the parts of the fp64 H x H control chain that rides in the pass launches
 (ctrl_end, SigmaA, lambda_max + loop test, SigmaB), stamped on the device.  `--shard-of N` runs rank 0's share of an N-rank
 job on one GPU; `--config cfg2|cfg4|cfg5` the other BASELINE shapes; `--full-cov` (with --config cfg5 --H <= 64) the

@@ -9,7 +9,7 @@ R=$GRAFT_REPO_ROOT
 for c in FETCH_SIZE WRITE_SIZE; do
   d=$R/gpurun_out/pmc_$(echo $c | tr A-Z a-z)
   rm -rf $d
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $d -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline > $d.log 2>&1 || { echo "rocprofv3 $c failed"; tail -5 $d.log; exit 1; }
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $d -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --settle-seconds 0 > $d.log 2>&1 || { echo "rocprofv3 $c failed"; tail -5 $d.log; exit 1; }
 done
 python3 - <<PY
 import csv, glob, collections

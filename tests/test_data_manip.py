@@ -1,6 +1,7 @@
 """Trajectory log (src/data_manip.jl:6-118) -- host-side twin in vbmatrixfactorization.jl_amd/data_manip.py.
-CPU-only: structure of the log, round trip through disk, and that the reference's OWN recorded log
-(examples/data/vbmf_test/log.jld -> tests/golden/vbmf_test.npz) is readable with extract_params_."""
+CPU-only: structure of the log, round trip through disk (the on-disk container is the reference's JLD/HDF5 layout,
+see tests/test_jld.py for the container itself), and that the arrays of the reference's OWN recorded log
+(examples/data/vbmf_test/log.jld, here as the npz extract tests/golden/vbmf_test.npz) are readable with extract_params_."""
 import numpy as np
 import pytest
 

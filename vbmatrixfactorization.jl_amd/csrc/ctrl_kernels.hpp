@@ -665,7 +665,11 @@ __device__ __forceinline__ void ctrl_end_dev(double* __restrict__ st, StateLayou
     double* ca = st + lay.ca();
     double* cb = st + lay.cb();
     double* scal = st + lay.scal();
-    const int stopped = load_stop(ints);
+    // Split schedule (flags & 64): the loop test of THIS sweep runs beside this function in another workgroup of the same
+    // launch (ctrl_loop_dev) and marks the stop flag with it_row + 1; CA/CB/sigma2 of the sweep it stops at are still due, so
+    // that value does not count as "stopped" here -- whichever of the two workgroups gets there first.
+    int stopped = load_stop(ints);
+    if ((flags & 64) && stopped == it_row + 1) stopped = 0;
     const int hme = threadIdx.x;                                 // H <= 256 <= blockDim.x: one diagonal entry per thread
     const double scv = hme < 32 ? scal[hme] : 0.0;
     const double trdot = st[lay.GX()];                           // tr(Y'BA') = sum (Y A) o BHat, summed where BHat was produced
@@ -776,7 +780,8 @@ __device__ __forceinline__ void ctrl_loop_dev(double* __restrict__ st, StateLayo
         if (trace) trace[4 * it_row + 0] = d;
         ints[I_ITERS] = it_row + 1;
         if (!(d > eps) || it_row + 1 >= ints[I_NITER])                      // NaN d exits too
-            __hip_atomic_store(ints + I_STOP, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ints + I_STOP, it_row + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // non-zero = stop; the
+                                                                            // value names the sweep (see ctrl_end_dev)
     }
     // (see ctrl_end_dev: no device-scope fence; the stop flag itself is an agent-scope atomic)
     __syncthreads();
