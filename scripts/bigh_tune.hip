@@ -124,21 +124,19 @@ int main(int argc, char** argv) {
         const Shape& sh = shapes[si];
         printf("== %s\n", sh.name);
         if (sh.H == 256) {
-            run_lds<8, 2, 2, 2, 3, 1>(sh, Y, F, O, obytes, si == 0 ? 6 : 1, "NH8 NXW2 lds DY3 GF1");
-            run_lds<8, 2, 2, 2, 4, 2>(sh, Y, F, O, obytes, si == 0 ? 6 : 1, "NH8 NXW2 lds DY4 GF2");
-            run_lds<8, 2, 2, 2, 6, 2>(sh, Y, F, O, obytes, si == 0 ? 6 : 1, "NH8 NXW2 lds DY6 GF2");
-            continue;
-            run_variant<8, 2, 2, 2>(sh, Y, F, O, obytes, "NH8 NXW2 DY2 DF2");
-            run_variant<8, 2, 2, 2, 1>(sh, Y, F, O, obytes, "NH8 NXW2 DY2 DF2 F L1-hot");
-            run_variant<8, 2, 2, 2, 2>(sh, Y, F, O, obytes, "NH8 NXW2 DY2 DF2 no F loads");
+            // round 2: ring depths again, now that the accumulators leave the AGPR file by explicit reads (no epilogue-induced
+            // register pressure in the loop): profiles/r02_g_bigh_ring_depths.txt
+            run_variant<8, 2, 2, 2>(sh, Y, F, O, obytes, "NH8 NXW2 DY2 DF2 (current)");
+            run_variant<8, 2, 3, 3>(sh, Y, F, O, obytes, "NH8 NXW2 DY3 DF3");
+            run_variant<8, 2, 4, 2>(sh, Y, F, O, obytes, "NH8 NXW2 DY4 DF2");
+            run_variant<8, 2, 6, 3>(sh, Y, F, O, obytes, "NH8 NXW2 DY6 DF3");
+            run_variant<8, 2, 6, 2>(sh, Y, F, O, obytes, "NH8 NXW2 DY6 DF2");
         } else {
-            run_lds<4, 4, 4, 2, 4, 2>(sh, Y, F, O, obytes, si == 2 ? 12 : 1, "NH4 NXW4 lds DY4 GF2");
-            run_lds<4, 4, 4, 2, 3, 1>(sh, Y, F, O, obytes, si == 2 ? 12 : 1, "NH4 NXW4 lds DY3 GF1");
-            run_lds<4, 4, 4, 2, 6, 3>(sh, Y, F, O, obytes, si == 2 ? 12 : 1, "NH4 NXW4 lds DY6 GF3");
-            continue;
-            run_variant<4, 4, 4, 2>(sh, Y, F, O, obytes, "NH4 NXW4 DY4 DF2");
-            run_variant<4, 4, 4, 2, 1>(sh, Y, F, O, obytes, "NH4 NXW4 DY4 DF2 F L1-hot");
-            run_variant<4, 4, 4, 2, 2>(sh, Y, F, O, obytes, "NH4 NXW4 DY4 DF2 no F loads");
+            run_variant<4, 4, 4, 2>(sh, Y, F, O, obytes, "NH4 NXW4 DY4 DF2 (current)");
+            run_variant<4, 4, 4, 4>(sh, Y, F, O, obytes, "NH4 NXW4 DY4 DF4");
+            run_variant<4, 4, 6, 3>(sh, Y, F, O, obytes, "NH4 NXW4 DY6 DF3");
+            run_variant<4, 4, 6, 2>(sh, Y, F, O, obytes, "NH4 NXW4 DY6 DF2");
+            run_variant<4, 4, 3, 3>(sh, Y, F, O, obytes, "NH4 NXW4 DY3 DF3");
         }
     }
     return 0;

@@ -57,6 +57,18 @@ __device__ __forceinline__ float bf2f(unsigned short u) {
     return __builtin_bit_cast(float, ((unsigned)u) << 16);
 }
 
+// One accumulator register taken out of the AGPR file at THIS point of the program.  Left to the compiler, every accumulator
+// value that is used by vector instructions after an MFMA loop is copied to a VGPR at the loop exit, all at once: with 256
+// accumulator registers per wave that runs the whole kernel -- the MFMA loop's operand rings included -- out of registers
+// (post_frag2_kernel: 1 484 bytes of scratch per lane -> 0, 256 -> 114 VGPRs).  The caller keeps >= 18 wait states between the
+// last MFMA and the first read (acc_read_fence): hand-placed reads are outside the compiler's hazard bookkeeping.
+__device__ __forceinline__ float acc_read(float a) {
+    float t;
+    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t) : "a"(a));
+    return t;
+}
+__device__ __forceinline__ void acc_read_fence() { asm volatile("s_nop 15\n\ts_nop 15"); }
+
 // PIPE_D: upper bound of the streaming kernel's ring depths (its run-ahead over-reads at most that many
 // tiles: every tiled buffer carries PIPE_D tiles of slack).  The actual padding quanta are per rank class
 // (host planner): x tiles to the per-wave tile count NXW = 8/NH, k-steps to the Y ring depth.

@@ -583,6 +583,246 @@ __global__ __launch_bounds__(256) void split_table_kernel(const float* __restric
     Sf[(combo * 2 + 1) * 64 + ln] = uint4{lo[0], lo[1], lo[2], lo[3]};
 }
 
+// ---- post_frag2: the H >= 128 factor update from a fragment-major product, software-pipelined (bf16 factor modes) ----------
+// Same contract and epilogue as post_frag_kernel's bf16 branch.  What changes is how the operands arrive.  post_frag_kernel
+// loaded each pair of table fragments right before the MFMAs that consume them -- 2 * NH * NH dependent L2 round trips per
+// wave (profiles/r02_pmc_mfma_cfg5.json: 7 % MFMA busy, 75 % of the wave cycles waiting; 215 us at 100k x 256 against ~75 us
+// of HBM time).  Here
+//   * the table is a LINEAR stream: split_table_kernel<NH, NT> lays the fragments out in exactly the order of use,
+//     [iteration = (hin, s2, h)][part][lane], and a D-deep register ring of iterations is refilled in place right after use
+//     (SGPR-offset buffer loads + sched_group_barrier, the streaming kernel's recipe, so the loads stay in flight across the
+//     loop); the run-ahead past the table is clamped to its last iteration;
+//   * the next h tile's 16 product registers per row tile are requested one whole hin step ahead;
+//   * NT = 3 parts per operand (bf16 hi + mid + lo carry all 24 significant bits of an fp32 value) and the six products with
+//     part indices i + j <= 2: what is dropped is 2^-24 relative, an fp32 rounding -- the EXACT product again, at 12 bf16 MFMAs
+//     of 32 cycles per 32 x 32 x 32 block where the exact-f32 MFMA needs 16 of 64.  (NT = 2, three products, is the round-1
+//     form: each product term then carries 2^-17, which B = Q inv(K_B) amplifies by cond(K_B).)
+// BSIDE = false: the A update (label mask, no delta tiles, no trace).
+template <int NT>
+__device__ __forceinline__ void split8_parts(const float* v, u32x4v (&part)[NT]) {
+    float r[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = v[e];
+#pragma unroll
+    for (int p = 0; p < NT; ++p) {
+        unsigned short b[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { b[e] = f2bf(r[e]); r[e] -= bf2f(b[e]); }
+        part[p] = u32x4v{b[0] | ((unsigned)b[1] << 16), b[2] | ((unsigned)b[3] << 16), b[4] | ((unsigned)b[5] << 16), b[6] | ((unsigned)b[7] << 16)};
+    }
+}
+
+// The Sigma / sigma2 table as pre-split bf16 MFMA fragments in order of use: [(hin, s2, h)][part < NT][lane] (1 KiB each)
+template <int NH, int NT>
+__global__ __launch_bounds__(256) void split_table_parts_kernel(const float* __restrict__ S, uint4* __restrict__ Sf,
+                                                                const int* __restrict__ stop) {
+    constexpr int Hp = NH * 32;
+    if (stop && *stop) return;
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= NH * 2 * NH * 64) return;
+    const int ln = w & 63, combo = w >> 6;
+    const int h = combo % NH, s2 = (combo / NH) & 1, hin = combo / (2 * NH);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = S[(long long)(hin * 32 + rho(8 * s2 + e, ln >> 5)) * Hp + h * 32 + (ln & 31)];
+    u32x4v part[NT];
+    split8_parts<NT>(v, part);
+#pragma unroll
+    for (int p = 0; p < NT; ++p) Sf[((long long)combo * NT + p) * 64 + ln] = uint4{part[p][0], part[p][1], part[p][2], part[p][3]};
+}
+
+template <int NH> struct PostFrag2Cfg { static constexpr int NXT = NH >= 8 ? 2 : 4; static constexpr int D = NH >= 8 ? 8 : 4; };
+
+// NXT: 32-row tiles per wave (PostFrag2Cfg<NH>::NXT on a long side, 1 on a short one: more workgroups)
+template <int MODE, int NH, int NXT, int NT, bool BSIDE>
+__global__ __launch_bounds__(256) void post_frag2_kernel(const float4* __restrict__ In4, const uint4* __restrict__ Sf,
+                                                         float* __restrict__ Fac, uint4* __restrict__ Ft,
+                                                         const unsigned char* __restrict__ mask, int hmask_start, int XT,
+                                                         const int* __restrict__ stop, double* __restrict__ trpart,
+                                                         uint4* __restrict__ Fd, int store_fac) {
+    static_assert(MODE != MODE_F32, "bf16 factor modes only (the fp32 mode keeps post_frag_kernel's exact-f32 MFMA)");
+    constexpr int Hp = NH * 32;
+    constexpr int D = PostFrag2Cfg<NH>::D;
+    constexpr int NIT = 2 * NH;                               // table iterations (s2, h) per hin
+    static_assert(NIT % D == 0, "ring slot = iteration mod D must not depend on hin");
+    __shared__ float tbuf[4][32 * TB_LD];
+    if (stop && *stop) return;
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int xt0 = (blockIdx.x * 4 + wib) * NXT;
+    if (xt0 >= XT) {
+        if (trpart && lane == 0) trpart[blockIdx.x * 4 + wib] = 0.0;
+        return;
+    }
+    // descriptors: the table stream, and each row tile's NH product blocks (4 KiB each, contiguous); tiles past XT (ragged last
+    // wave) read tile XT-1 again and are dropped at the store
+    const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc((void*)Sf, 0, (unsigned)(NH * NIT * NT) * 1024u, 0x00020000);
+    __amdgpu_buffer_rsrc_t qrs[NXT];
+#pragma unroll
+    for (int i = 0; i < NXT; ++i) {
+        const int xt = xt0 + i < XT ? xt0 + i : XT - 1;
+        qrs[i] = __builtin_amdgcn_make_buffer_rsrc((void*)(In4 + (long long)xt * NH * 256), 0, (unsigned)NH * 4096u, 0x00020000);
+    }
+    const int tvo = lane * 16, qvo = lane * 64;
+
+    f32x16 acc[NXT][NH];
+#pragma unroll
+    for (int i = 0; i < NXT; ++i)
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][h][r] = 0.f;
+
+    u32x4v tb[D][NT];
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+#pragma unroll
+        for (int p = 0; p < NT; ++p) tb[d][p] = __builtin_amdgcn_raw_buffer_load_b128(trs, tvo, (d * NT + p) * 1024, 0);
+    u32x4v qc[NXT][4];
+#pragma unroll
+    for (int i = 0; i < NXT; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) qc[i][q] = __builtin_amdgcn_raw_buffer_load_b128(qrs[i], qvo + q * 16, 0, 0);
+
+    for (int hin = 0; hin < NH; ++hin) {
+        // (the SGPR offset is not part of the descriptor's bounds check, so run-ahead is clamped, not left to it)
+        const int hnext = hin + 1 < NH ? hin + 1 : hin;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            u32x4v ap[NXT][NT];
+#pragma unroll
+            for (int i = 0; i < NXT; ++i) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const unsigned w = qc[i][2 * s2 + (e >> 2)][e & 3];
+                    v[e] = bitsf(w);
+                }
+                split8_parts<NT>(v, ap[i]);
+            }
+            if (s2 == 1) {
+                // the product registers are dead once split: the next h tile's 16 per row tile are requested into them now, half a
+                // hin step (8 NH MFMA groups) ahead of their use (the last step re-reads its own block: never used)
+#pragma unroll
+                for (int i = 0; i < NXT; ++i)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) qc[i][q] = __builtin_amdgcn_raw_buffer_load_b128(qrs[i], qvo + q * 16, hnext * 4096, 0);
+            }
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                const int it = s2 * NH + h, slot = it % D;
+                const int itn = min(hin * NIT + it + D, NH * NIT - 1);       // run-ahead past the table re-reads its last iteration
+#pragma unroll
+                for (int pa = 0; pa < NT; ++pa)
+#pragma unroll
+                    for (int pb = 0; pa + pb < NT; ++pb)
+#pragma unroll
+                        for (int i = 0; i < NXT; ++i)
+                            acc[i][h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ap[i][pa]),
+                                                                               __builtin_bit_cast(bf16x8, tb[slot][pb]), acc[i][h], 0, 0, 0);
+#pragma unroll
+                for (int p = 0; p < NT; ++p)
+                    tb[slot][p] = __builtin_amdgcn_raw_buffer_load_b128(trs, tvo, (itn * NT + p) * 1024, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, NXT * (NT * (NT + 1) / 2), 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, NT, 0);
+            }
+        }
+    }
+
+    // accumulator layout: lane (c = h' in tile, half), register r -> row x0 + rho(r, half)
+    // (the store addresses are derived from an opaque copy of the lane id: computed up front, as the optimiser would, the 16
+    //  blocks' row pointers live across the main loop and push its operand rings into scratch)
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    acc_read_fence();                                        // the last MFMA's result is read below by hand-placed AGPR reads
+    const int c = lane_e & 31, half = lane_e >> 5;
+    double tr = 0.0;
+    float* tbw = tbuf[wib];
+    const bool want_tr = BSIDE && trpart != nullptr;
+    const bool want_old = BSIDE && Fd != nullptr;
+    constexpr int NPART = ModeTraits<MODE>::NPART;
+    constexpr int NB = NXT * NH;                             // 32 x 32 blocks of this wave, b = i * NH + h
+    // ONE block at a time, everything that needs its accumulator tile inside (mask, operand tiles, delta tiles, fp32 store,
+    // tr(B'YA) share): a tile that had to survive until a later loop is 16 more live registers per block.  What a block READS
+    // (its previous operand tiles for the delta, its product fragments again for the trace: L2-hot) is requested one block
+    // ahead, so the round trip overlaps the block before.
+    uint4 on[2 * NPART], oc[2 * NPART];
+    float4 qn[4], qc4[4];
+    auto request = [&](int b) __attribute__((always_inline)) {
+        const int i = b / NH, h = b % NH;
+        const int xt = xt0 + i < XT ? xt0 + i : XT - 1;
+        if (want_old) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int pa = 0; pa < NPART; ++pa) on[s * NPART + pa] = Ft[(((long long)(2 * xt + s) * NPART + pa) * NH + h) * 64 + lane_e];
+        }
+        if (want_tr) {
+            const float4* t4 = In4 + (((long long)xt * NH + h) * 64 + lane_e) * 4;
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) qn[qd] = t4[qd];
+        }
+    };
+    request(0);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int i = b / NH, h = b % NH;
+        const int xt = xt0 + i;
+        if (xt >= XT) break;
+        const long long x0 = (long long)xt * 32;
+        const int hcol = h * 32 + c;
+#pragma unroll
+        for (int u = 0; u < 2 * NPART; ++u) oc[u] = on[u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) qc4[u] = qn[u];
+        if (b + 1 < NB) request(b + 1);
+        // (the tile is taken out of the accumulation registers HERE: common.hpp, acc_read)
+        f32x16 a;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float src = acc[i][h][r];
+            a[r] = acc_read(src);
+        }
+        if constexpr (!BSIDE) {
+            if (mask != nullptr && hcol >= hmask_start) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (mask[x0 + rho(r, half)]) a[r] = 0.f;
+            }
+        }
+        // Fd (B side): old - new of this block as delta tiles; the old block is what the operand tiles held (read above, before
+        // they are overwritten here).  store_fac = 0 (inside the run loops): no fp32 copy per sweep.
+        write_factor_tiles<MODE, NH>(Ft, a, xt, h, lane_e);
+        if (want_old) {
+            f32x16 oldv;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const unsigned hw[4] = {oc[s * NPART].x, oc[s * NPART].y, oc[s * NPART].z, oc[s * NPART].w};
+                unsigned lw[4] = {0u, 0u, 0u, 0u};
+                if constexpr (NPART == 2) { lw[0] = oc[s * NPART + 1].x; lw[1] = oc[s * NPART + 1].y; lw[2] = oc[s * NPART + 1].z; lw[3] = oc[s * NPART + 1].w; }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float f = bf2f((unsigned short)(hw[e >> 1] >> (16 * (e & 1))));
+                    if constexpr (NPART == 2) f += bf2f((unsigned short)(lw[e >> 1] >> (16 * (e & 1))));
+                    oldv[8 * s + e] = f;
+                }
+            }
+            write_delta_tiles<NH>(Fd, oldv, a, xt, h, lane_e);
+        }
+        if (store_fac) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Fac[(x0 + rho(r, half)) * Hp + hcol] = a[r];
+        }
+        if (want_tr) {
+            float q[16];
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) { q[4 * qd] = qc4[qd].x; q[4 * qd + 1] = qc4[qd].y; q[4 * qd + 2] = qc4[qd].z; q[4 * qd + 3] = qc4[qd].w; }
+            tr += (double)tile_dot_qb<true>(q, a, tbw, lane_e);
+        }
+    }
+    if (want_tr) store_wave_dot(tr, trpart + blockIdx.x * 4 + wib, lane_e);
+}
+
 // ---- fused post + Gram (NH <= 2), second form: the tile body of the register epilogue as its own kernel ------------------
 // For products that did go through HBM: Y'B always (split-K slabs, summed by slab_sum / all-reduced over the ranks before), Y*A
 // when that pass is split (short row shards, narrow problems).  `In` is ONE fragment-major product (stream_gemm.hpp, frag_out):
@@ -906,6 +1146,114 @@ __global__ __launch_bounds__(256) void gram_tiles_kernel(const uint4* __restrict
                 if (h1 != h2) o[j * Hp + i] = G[qq][r];
             }
         }
+}
+
+// gram_tiles2: the tile Gram with its operand fragments PREFETCHED -- gram_tiles_kernel<., ., 0> loaded a 16-row step's
+// fragments, waited, multiplied, and only then asked for the next step: one exposed HBM round trip per step and workgroup
+// (profiles/r02_pmc_mfma_cfg5.json: 13 % MFMA busy; 66 us for the 102 MB of B tiles at 100k x 256, 20 us of HBM time).  Here a
+// DR-deep register ring of steps is refilled in place right after use (buffer loads + sched_group_barrier, as in the streaming
+// kernel); the step offset travels in the VGPR offset, so steps past the chunk's end are out of the descriptor's range and
+// arrive as zeros (they add nothing) -- no remainder loop.  The wave's pair set is a template parameter (straight-line code per
+// wave instead of 36 wave-uniform branches per step).  Gram of `Ft` into slab half 0 and, if given, of the delta tiles `Fd`
+// (two parts) into slab half 1, in ONE launch.  Same slab format and the same MFMA order per pair as gram_tiles_kernel.
+template <int NH, int W> constexpr int gram_pairs_of_wave() {
+    int n = 0, p = 0;
+    for (int h1 = 0; h1 < NH; ++h1)
+        for (int h2 = h1; h2 < NH; ++h2, ++p)
+            if ((p & 3) == W) ++n;
+    return n;
+}
+template <int NH, int NPART, int W>
+__device__ __forceinline__ void gram_tiles_body(const uint4* __restrict__ Ft, float* __restrict__ o, int t0, int t1, int lane) {
+    constexpr int Hp = NH * 32;
+    constexpr int NPAIR = NH * (NH + 1) / 2;
+    constexpr int PW = (NPAIR + 3) / 4;
+    constexpr int DR = NH >= 8 ? 3 : 6;
+    constexpr int NM = gram_pairs_of_wave<NH, W>() * NPART * NPART;
+    constexpr unsigned STEP_BYTES = (unsigned)NPART * NH * 1024u;
+    const int nsteps = 2 * (t1 - t0);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(Ft + (long long)t0 * 2 * NPART * NH * 64), 0,
+                                                                        (unsigned)nsteps * STEP_BYTES, 0x00020000);
+    f32x16 G[PW];
+#pragma unroll
+    for (int q = 0; q < PW; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) G[q][r] = 0.f;
+    u32x4v f[DR][NH][NPART];
+#pragma unroll
+    for (int d = 0; d < DR; ++d) {
+        const int vo = lane * 16 + d * (int)STEP_BYTES;
+#pragma unroll
+        for (int pa = 0; pa < NPART; ++pa)
+#pragma unroll
+            for (int h = 0; h < NH; ++h) f[d][h][pa] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, (pa * NH + h) * 1024, 0);
+    }
+    for (int s0 = 0; s0 < nsteps; s0 += DR) {
+#pragma unroll
+        for (int d = 0; d < DR; ++d) {
+            int p = 0;
+#pragma unroll
+            for (int h1 = 0; h1 < NH; ++h1)
+#pragma unroll
+                for (int h2 = h1; h2 < NH; ++h2, ++p) {
+                    if ((p & 3) != W) continue;              // compile-time after unrolling
+                    const int qq = p >> 2;
+#pragma unroll
+                    for (int pa = 0; pa < NPART; ++pa)
+#pragma unroll
+                        for (int pb = 0; pb < NPART; ++pb)
+                            G[qq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f[d][h1][pa]),
+                                                                            __builtin_bit_cast(bf16x8, f[d][h2][pb]), G[qq], 0, 0, 0);
+                }
+            const int vo = lane * 16 + (s0 + d + DR) * (int)STEP_BYTES;
+#pragma unroll
+            for (int pa = 0; pa < NPART; ++pa)
+#pragma unroll
+                for (int h = 0; h < NH; ++h) f[d][h][pa] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, (pa * NH + h) * 1024, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, NH * NPART, 0);
+        }
+    }
+    int lane_e = lane;                                       // (store addresses from an opaque copy: not hoisted over the loop)
+    asm volatile("" : "+v"(lane_e));
+    const int c = lane_e & 31, half = lane_e >> 5;
+    int p = 0;
+#pragma unroll
+    for (int h1 = 0; h1 < NH; ++h1)
+#pragma unroll
+        for (int h2 = h1; h2 < NH; ++h2, ++p) {
+            if ((p & 3) != W) continue;
+            const int qq = p >> 2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long i = h1 * 32 + rho(r, half), j = h2 * 32 + c;
+                o[i * Hp + j] = G[qq][r];
+                if (h1 != h2) o[j * Hp + i] = G[qq][r];
+            }
+        }
+}
+template <int NH, int NPART, int W>
+__device__ __forceinline__ void gram_tiles_job(const uint4* __restrict__ Ft, const uint4* __restrict__ Fd, float* __restrict__ o,
+                                               int t0, int t1, int lane) {
+    gram_tiles_body<NH, NPART, W>(Ft, o, t0, t1, lane);
+    if (Fd != nullptr) gram_tiles_body<NH, 2, W>(Fd, o + NH * 32 * NH * 32, t0, t1, lane);
+}
+template <int NH, int NPART>
+__global__ __launch_bounds__(256) void gram_tiles2_kernel(const uint4* __restrict__ Ft, const uint4* __restrict__ Fd,
+                                                          float* __restrict__ slabs, int XT, int tiles_per_chunk,
+                                                          const int* __restrict__ stop) {
+    constexpr int Hp = NH * 32;
+    if (stop && *stop) return;
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int chunk = blockIdx.x;
+    const int t0 = chunk * tiles_per_chunk;
+    const int t1 = min(XT, t0 + tiles_per_chunk);
+    float* o = slabs + (long long)chunk * 2 * Hp * Hp;
+    if (wib == 0) gram_tiles_job<NH, NPART, 0>(Ft, Fd, o, t0, t1, lane);
+    else if (wib == 1) gram_tiles_job<NH, NPART, 1>(Ft, Fd, o, t0, t1, lane);
+    else if (wib == 2) gram_tiles_job<NH, NPART, 2>(Ft, Fd, o, t0, t1, lane);
+    else gram_tiles_job<NH, NPART, 3>(Ft, Fd, o, t0, t1, lane);
 }
 
 // out[which][i] = sum_chunk slabs[chunk][which][i]  (fp64).  which in {0: Gram, 1: delta-Gram}.

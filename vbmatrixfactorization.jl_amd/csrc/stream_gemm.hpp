@@ -341,26 +341,42 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const uint4* __restric
         // Fragment-major product for the H >= 128 post kernel: tile (x tile, h tile) is 64 lanes x 16 registers, each lane's
         // registers contiguous -- four 16-byte stores per tile here and four 16-byte loads there, instead of sixteen 4-byte
         // row accesses on both sides (the consumer takes register r as the operand of MFMA step r: post_frag_kernel).
+        // (H >= 128: the accumulators leave the AGPR file by explicit reads, tile by tile -- common.hpp, acc_read)
         float4* o4 = reinterpret_cast<float4*>(Out + (long long)split * (NH * 32) * ldOut);
+        if constexpr (FINE) acc_read_fence();
 #pragma unroll
         for (int i = 0; i < NXW_; ++i)
 #pragma unroll
             for (int h = 0; h < NH; ++h) {
                 float4* t = o4 + (((long long)(xg * NXW_ + i) * NH + h) * 64 + lane) * 4;
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    t[q] = float4{acc[i][h][4 * q], acc[i][h][4 * q + 1], acc[i][h][4 * q + 2], acc[i][h][4 * q + 3]};
+                for (int q = 0; q < 4; ++q) {
+                    if constexpr (FINE) {
+                        const float a0 = acc[i][h][4 * q], a1 = acc[i][h][4 * q + 1], a2 = acc[i][h][4 * q + 2], a3 = acc[i][h][4 * q + 3];
+                        t[q] = float4{acc_read(a0), acc_read(a1), acc_read(a2), acc_read(a3)};
+                    } else {
+                        t[q] = float4{acc[i][h][4 * q], acc[i][h][4 * q + 1], acc[i][h][4 * q + 2], acc[i][h][4 * q + 3]};
+                    }
+                }
             }
     } else {
         const int c = lane & 31, half = lane >> 5;
         float* o = Out + (long long)split * (NH * 32) * ldOut;
+        if constexpr (FINE) acc_read_fence();
 #pragma unroll
         for (int i = 0; i < NXW_; ++i) {
             const long long x = (long long)(xg * NXW_ + i) * 32 + c;
 #pragma unroll
             for (int h = 0; h < NH; ++h)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[(long long)(h * 32 + rho(r, half)) * ldOut + x] = acc[i][h][r];
+                for (int r = 0; r < 16; ++r) {
+                    if constexpr (FINE) {
+                        const float a = acc[i][h][r];
+                        o[(long long)(h * 32 + rho(r, half)) * ldOut + x] = acc_read(a);
+                    } else {
+                        o[(long long)(h * 32 + rho(r, half)) * ldOut + x] = acc[i][h][r];
+                    }
+                }
         }
     }
 }

@@ -441,26 +441,62 @@ static bool fused_gram(const vbmf_ctx* c) { return c->NH <= 2; }
 
 static int launch_pair_reduce(vbmf_ctx* c, int which, int nslab, int ntr = 0);
 
-// B from a fragment-major product (H >= 128, un-split Y*A pass)
-static int launch_post_frag(vbmf_ctx* c) {
-    const Dims& d = c->d2;
-    const int nxt = c->NH >= 8 ? VBMF_POST_NXT8 : 1;                          // = PostCfg<NH>::NXT
-    const int grid = (cdiv(d.XT, nxt) + 3) / 4;
-    double* trp = (!c->diagvar && 4 * grid <= c->trpart_cap) ? c->trpart : nullptr;
-    c->ntr = trp ? 4 * grid : 0;
-    uint4* fd = c->FD;
-    const int store_fac = (fd != nullptr && c->in_run) ? 0 : 1;
-    c->fd_valid = fd != nullptr;
-    if (!store_fac) c->B32_stale = true;
-    if (c->SBf != nullptr) {
-        const int nthr = c->NH * 2 * c->NH * 64;
-        if (c->NH == 4) hipLaunchKernelGGL((split_table_kernel<4>), dim3((nthr + 255) / 256), dim3(256), 0, c->stream, c->SB32, c->SBf, c->ints + I_STOP);
-        else hipLaunchKernelGGL((split_table_kernel<8>), dim3((nthr + 255) / 256), dim3(256), 0, c->stream, c->SB32, c->SBf, c->ints + I_STOP);
+// A (which = 0) or B (which = 1) from ONE fragment-major product (H >= 128): bf16 factor modes run the software-pipelined
+// post_frag2_kernel on a table pre-split into VBMF_POST_NT bf16 parts in order of use; the fp32 mode keeps the exact-f32 kernel
+#ifndef VBMF_POST_NT
+#define VBMF_POST_NT 3            // 3: six-term product (exact to an fp32 rounding); 2: round 1's three-term product (2^-17 per term)
+#endif
+static bool frag_post(const vbmf_ctx* c) { return c->NH >= 4 && c->mode != MODE_F32; }
+static int launch_post_frag(vbmf_ctx* c, int which = 1, const float* In = nullptr) {
+    const Dims& d = which == 0 ? c->d1 : c->d2;
+    const float* S = which == 0 ? c->SA32 : c->SB32;
+    float* Fac = which == 0 ? c->A32 : c->B32[c->bcur ^ 1];
+    uint4* Ft = which == 0 ? c->FA : c->FB;
+    if (In == nullptr) In = c->Q;
+    const int* stop = c->ints + I_STOP;
+    if (c->mode == MODE_F32) {
+        if (which != 1) FAIL(c, VBMF_ERR_INVALID, "fragment-major A update in the fp32 mode");
+        const int nxt = c->NH >= 8 ? VBMF_POST_NXT8 : 1;                          // = PostCfg<NH>::NXT
+        const int grid = (cdiv(d.XT, nxt) + 3) / 4;
+        double* trp = (!c->diagvar && 4 * grid <= c->trpart_cap) ? c->trpart : nullptr;
+        c->ntr = trp ? 4 * grid : 0;
+        c->fd_valid = false;
+        if (c->NH == 4) hipLaunchKernelGGL((post_frag_kernel<MODE_F32, 4>), dim3(grid), dim3(256), 0, c->stream, (const float4*)In, S, Fac, Ft, (const unsigned char*)nullptr, 0, d.XT, stop, trp, (uint4*)nullptr, 1, (const uint4*)nullptr);
+        else hipLaunchKernelGGL((post_frag_kernel<MODE_F32, 8>), dim3(grid), dim3(256), 0, c->stream, (const float4*)In, S, Fac, Ft, (const unsigned char*)nullptr, 0, d.XT, stop, trp, (uint4*)nullptr, 1, (const uint4*)nullptr);
+        HIPCHK(c, hipGetLastError());
+        return VBMF_OK;
     }
+    // row tiles per wave: 256 accumulator registers' worth on the long side; ONE on a short side (the 10k-row A side would
+    // otherwise occupy 20 workgroups)
+    const bool short_side = d.XT < 2048;
+    const int nxt = short_side ? 1 : (c->NH >= 8 ? 2 : 4);                          // = PostFrag2Cfg<NH>::NXT
+    const int grid = (cdiv(d.XT, nxt) + 3) / 4;
+    double* trp = (which == 1 && !c->diagvar && 4 * grid <= c->trpart_cap) ? c->trpart : nullptr;
+    if (which == 1) c->ntr = trp ? 4 * grid : 0;
+    uint4* fd = which == 1 ? c->FD : nullptr;
+    const int store_fac = (fd != nullptr && c->in_run) ? 0 : 1;
+    if (which == 1) c->fd_valid = fd != nullptr;
+    if (!store_fac) c->B32_stale = true;
+    const unsigned char* mk = (which == 0 && c->has_mask) ? c->mask : nullptr;
+    const int hstart = (int)(c->H - c->H1);
+    const int nthr = c->NH * 2 * c->NH * 64;
+    if (c->NH == 4) hipLaunchKernelGGL((split_table_parts_kernel<4, VBMF_POST_NT>), dim3((nthr + 255) / 256), dim3(256), 0, c->stream, S, c->SBf, stop);
+    else hipLaunchKernelGGL((split_table_parts_kernel<8, VBMF_POST_NT>), dim3((nthr + 255) / 256), dim3(256), 0, c->stream, S, c->SBf, stop);
+#define POST_FRAG2(NHc_, NXTc_, BS_)                                                                                              \
+    hipLaunchKernelGGL((post_frag2_kernel<MODEc, NHc_, NXTc_, VBMF_POST_NT, BS_>), dim3(grid), dim3(256), 0, c->stream,           \
+                       (const float4*)In, (const uint4*)c->SBf, Fac, Ft, mk, hstart, d.XT, stop, trp, fd, store_fac)
     DISPATCH_MODE(c->mode, {
-        if (c->NH == 4) hipLaunchKernelGGL((post_frag_kernel<MODEc, 4>), dim3(grid), dim3(256), 0, c->stream, (const float4*)c->Q, c->SB32, c->B32[c->bcur ^ 1], c->FB, (const unsigned char*)nullptr, 0, d.XT, c->ints + I_STOP, trp, fd, store_fac, (const uint4*)c->SBf);
-        else hipLaunchKernelGGL((post_frag_kernel<MODEc, 8>), dim3(grid), dim3(256), 0, c->stream, (const float4*)c->Q, c->SB32, c->B32[c->bcur ^ 1], c->FB, (const unsigned char*)nullptr, 0, d.XT, c->ints + I_STOP, trp, fd, store_fac, (const uint4*)c->SBf);
+        if constexpr (MODEc != MODE_F32) {
+            if (which == 0) {
+                if (c->NH == 4) { if (short_side) POST_FRAG2(4, 1, false); else POST_FRAG2(4, 4, false); }
+                else { if (short_side) POST_FRAG2(8, 1, false); else POST_FRAG2(8, 2, false); }
+            } else {
+                if (c->NH == 4) { if (short_side) POST_FRAG2(4, 1, true); else POST_FRAG2(4, 4, true); }
+                else { if (short_side) POST_FRAG2(8, 1, true); else POST_FRAG2(8, 2, true); }
+            }
+        }
     });
+#undef POST_FRAG2
     HIPCHK(c, hipGetLastError());
     return VBMF_OK;
 }
@@ -526,10 +562,19 @@ static int launch_retile(vbmf_ctx* c, int which, bool gated = false) {
     return launch_retile_ex(c, which, which == 0 ? c->A32 : c->B32[c->bcur], which == 0 ? c->FA : c->FB, nullptr, 1, gated);
 }
 
+// 32-row tiles per Gram chunk (= per workgroup) of side `which`.  H >= 128: a chunk's slab is 2 Hp^2 floats (512 KiB at H = 256), so
+// the long side keeps >= 16 tiles per chunk (the slab traffic of the reduction); a SHORT side (the 10k-row A side: 313 tiles) would
+// then fill 20 CUs only -- it takes 4 tiles per chunk or more (measured at 10k x 256: 40 -> see DESIGN.md section 7).
+static int gram_tiles_per_chunk(const vbmf_ctx* c, int which) {
+    if (c->NH < 4) return c->tiles_per_chunk;
+    const int XT = which == 0 ? c->d1.XT : c->d2.XT;
+    return XT >= 2048 ? c->tiles_per_chunk : std::max(4, cdiv(XT, 96));
+}
 // Gram of A (which=0) or of B with optional delta-Gram against prev (which=1) into the state block.
 static int launch_gram(vbmf_ctx* c, int which, const float* cur, const float* prev, bool gated, int ntr = 0) {
     const Dims& d = which == 0 ? c->d1 : c->d2;
-    const int nchunk = cdiv(d.XT, c->tiles_per_chunk);
+    const int tpc = gram_tiles_per_chunk(c, which);
+    const int nchunk = cdiv(d.XT, tpc);
     const int nw = nchunk * c->NH * c->NH;
     const int* stop = gated ? c->ints + I_STOP : nullptr;
     // H >= 128 with a bf16 factor: from the operand tiles with bf16 MFMAs (the tiles of `cur` are current whenever a
@@ -542,14 +587,15 @@ static int launch_gram(vbmf_ctx* c, int which, const float* cur, const float* pr
         const bool from_fd = which == 1 && prev != nullptr && c->fd_valid && c->FD != nullptr;
 #define GRAM_TILES(NHc_, NPc_)                                                                                               \
     do {                                                                                                                         \
-        hipLaunchKernelGGL((gram_tiles_kernel<NHc_, NPc_, 0>), dim3(nchunk), dim3(256), 0, c->stream, Ft, prev, c->gslab, d.XT,   \
-                           c->tiles_per_chunk, stop, 0);                                                                         \
-        if (from_fd)                                                                                                             \
-            hipLaunchKernelGGL((gram_tiles_kernel<NHc_, 2, 0>), dim3(nchunk), dim3(256), 0, c->stream, (const uint4*)c->FD, prev,  \
-                               c->gslab, d.XT, c->tiles_per_chunk, stop, 1);                                                     \
-        else if (prev != nullptr)                                                                                                \
+        if (from_fd || prev == nullptr) {                                                                                        \
+            hipLaunchKernelGGL((gram_tiles2_kernel<NHc_, NPc_>), dim3(nchunk), dim3(256), 0, c->stream, Ft,                        \
+                               from_fd ? (const uint4*)c->FD : (const uint4*)nullptr, c->gslab, d.XT, tpc, stop);  \
+        } else {                                                                                                                 \
+            hipLaunchKernelGGL((gram_tiles_kernel<NHc_, NPc_, 0>), dim3(nchunk), dim3(256), 0, c->stream, Ft, prev, c->gslab,      \
+                               d.XT, tpc, stop, 0);                                                               \
             hipLaunchKernelGGL((gram_tiles_kernel<NHc_, NPc_, 1>), dim3(nchunk), dim3(256), 0, c->stream, Ft, prev, c->gslab,      \
-                               d.XT, c->tiles_per_chunk, stop, 1);                                                               \
+                               d.XT, tpc, stop, 1);                                                               \
+        }                                                                                                                        \
     } while (0)
         if (c->NH == 4) { if (c->npart == 2) GRAM_TILES(4, 2); else GRAM_TILES(4, 1); }
         else { if (c->npart == 2) GRAM_TILES(8, 2); else GRAM_TILES(8, 1); }
@@ -557,7 +603,7 @@ static int launch_gram(vbmf_ctx* c, int which, const float* cur, const float* pr
     } else {
         DISPATCH_NH(c->NH, {
             hipLaunchKernelGGL((gram_kernel<NHc>), dim3((nw + 3) / 4), dim3(256), 0, c->stream, cur, prev, c->gslab, d.XT,
-                               c->tiles_per_chunk, nchunk, stop);
+                               tpc, nchunk, stop);
         });
     }
     const int n = c->Hp * c->Hp;
@@ -702,7 +748,7 @@ static int do_update_A(vbmf_ctx* c, bool reuse_P = false) {
     if (have_P) {
         TRY(launch_ctrl_cov(c, 0));
     } else if (fused_ctrl(c)) {
-        c->P_frag = fused_gram(c);           // H <= 64: Y'B travels fragment-major to post_gram (16-byte accesses)
+        c->P_frag = fused_gram(c) || frag_post(c);   // Y'B travels fragment-major to the post kernel (16-byte accesses)
         TRY(launch_stream(c, 0, CTRL_COV_A | (c->tail_pending ? CTRL_PREV_END : 0), false, nullptr, c->P_frag));
         if (c->tail_pending) ++c->ends_enqueued;
         c->tail_pending = false;
@@ -719,10 +765,11 @@ static int do_update_A(vbmf_ctx* c, bool reuse_P = false) {
         TRY(side_fork(c));
         TRY(launch_ctrl_cov(c, 0));
         TRY(side_end(c));
-        TRY(launch_stream(c, 0));
+        c->P_frag = frag_post(c);
+        TRY(launch_stream(c, 0, 0, false, nullptr, c->P_frag));
     } else {
         TRY(launch_ctrl_cov(c, 0));
-        c->P_frag = fused_gram(c);
+        c->P_frag = fused_gram(c) || frag_post(c);
         TRY(launch_stream(c, 0, 0, false, nullptr, c->P_frag));
     }
     if (sharded(c) || c->d1.nsplit > 1) {
@@ -742,10 +789,12 @@ static int do_update_A(vbmf_ctx* c, bool reuse_P = false) {
         }
         TRY(side_join(c));
         if (fused_gram(c)) TRY(launch_post_gram(c, 0, c->Pred));
+        else if (c->P_frag) TRY(launch_post_frag(c, 0, c->Pred));
         else TRY(launch_post(c, 0, c->Pred, 1));
     } else {
         TRY(side_join(c));
         if (fused_gram(c)) TRY(launch_post_gram(c, 0, c->P));
+        else if (c->P_frag) TRY(launch_post_frag(c, 0, c->P));
         else TRY(launch_post(c, 0, c->P, 1));
     }
     if (!fused_gram(c)) TRY(launch_gram(c, 0, c->A32, nullptr, true));
@@ -1022,7 +1071,7 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
     ALLOC(c->Y1, c->nY1 * 16);
     ALLOC(c->Y2, c->nY2 * 16);
     ALLOC(c->FB_alloc, (c->nFB + flead) * 16);
-    if (c->NH >= 4 && c->mode != MODE_F32) ALLOC(c->SBf, (size_t)c->NH * 2 * c->NH * 2 * 64 * 16);
+    if (c->NH >= 4 && c->mode != MODE_F32) ALLOC(c->SBf, (size_t)c->NH * 2 * c->NH * VBMF_POST_NT * 64 * 16);
     if (c->NH >= 4 && c->mode != MODE_F32 && !c->diagvar)
         ALLOC(c->FD, ((size_t)c->d1.KS + PIPE_D) * 2 * c->NH * 64 * 16);
     ALLOC(c->FA_alloc, (c->nFA + flead) * 16);
@@ -1036,7 +1085,7 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
     ALLOC(c->B32[1], (size_t)c->Lp * c->Hp * 4);
     ALLOC(c->SA32, (size_t)c->Hp * c->Hp * 4);
     ALLOC(c->SB32, (size_t)c->Hp * c->Hp * 4);
-    const int nchunk = std::max(cdiv(c->d1.XT, c->tiles_per_chunk), cdiv(c->d2.XT, c->tiles_per_chunk));
+    const int nchunk = std::max(cdiv(c->d1.XT, gram_tiles_per_chunk(c, 0)), cdiv(c->d2.XT, gram_tiles_per_chunk(c, 1)));
     // Gram partial slabs: one per chunk (generic path), per post_gram workgroup (<= 256), or per pass-2 workgroup when the
     // pass carries the register epilogue (capped at 1024 slabs = 24 MB; longer shards use the separate post kernel)
     {
@@ -1817,6 +1866,7 @@ static int do_sparse_update_A(vbmf_ctx* c, bool reuse_P = false) {
         reuse_P = false;                            // sigma changes every iteration, so does Y' diag(sigma) B
     }
     if (!(reuse_P && c->P_valid)) {
+        c->P_frag = false;                          // the element-wise A update reads the plain [h][m] product
         TRY(launch_stream(c, 0));
         const long long n = (long long)c->Hp * c->d1.XT * 32;
         hipLaunchKernelGGL(slab_sum_kernel, dim3(grid_for(n / 4, 256, 2048)), dim3(256), 0, c->stream, c->P, c->d1.nsplit, n,
