@@ -125,6 +125,8 @@ def main():
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    # (multi-process GPU work on this pool needs dmabuf IPC; the image exports it already -- kept here for a bare environment)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

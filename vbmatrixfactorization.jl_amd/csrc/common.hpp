@@ -57,17 +57,32 @@ __device__ __forceinline__ float bf2f(unsigned short u) {
     return __builtin_bit_cast(float, ((unsigned)u) << 16);
 }
 
-// One accumulator register taken out of the AGPR file at THIS point of the program.  Left to the compiler, every accumulator
-// value that is used by vector instructions after an MFMA loop is copied to a VGPR at the loop exit, all at once: with 256
-// accumulator registers per wave that runs the whole kernel -- the MFMA loop's operand rings included -- out of registers
-// (post_frag2_kernel: 1 484 bytes of scratch per lane -> 0, 256 -> 114 VGPRs).  The caller keeps >= 18 wait states between the
-// last MFMA and the first read (acc_read_fence): hand-placed reads are outside the compiler's hazard bookkeeping.
-__device__ __forceinline__ float acc_read(float a) {
-    float t;
-    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(t) : "a"(a));
-    return t;
+// One 32 x 32 accumulator tile (16 registers) taken out of the AGPR file at THIS point of the program.  Left to the compiler,
+// every accumulator value that is used by vector instructions after an MFMA loop is copied to a VGPR at the loop exit, all at
+// once: with 256 accumulator registers per wave that runs the whole kernel -- the MFMA loop's operand rings included -- out of
+// registers (post_frag2_kernel: 1 484 bytes of scratch per lane -> 0, 256 -> 114 VGPRs).
+// Hand-placed v_accvgpr_read is outside the compiler's hazard bookkeeping (an MFMA result may be read by a vector instruction
+// only >= 18 wait states after the MFMA issued), and the scheduler is free to move an MFMA -- a pure register operation -- past a
+// separate "wait" statement.  So the wait states live INSIDE the statement that reads: its inputs are registers of the tile,
+// which every MFMA of that tile writes, so all of them issue before it, and it begins with 32 wait states.  (First version: a
+// separate s_nop statement before the reads; with the MFMA loop fully unrolled the last, smallest product terms were then
+// sometimes missing from the value read -- seen as 1e-6 differences of a replicated factor between ranks.)
+__device__ __forceinline__ void acc_read_tile(const f32x16& src, f32x16& dst) {
+    float o[16];
+    const float i0 = src[0], i1 = src[1], i2 = src[2], i3 = src[3], i4 = src[4], i5 = src[5], i6 = src[6], i7 = src[7];
+    const float i8 = src[8], i9 = src[9], i10 = src[10], i11 = src[11], i12 = src[12], i13 = src[13], i14 = src[14], i15 = src[15];
+    asm volatile("s_nop 15\n\ts_nop 15\n\t"
+                 "v_accvgpr_read_b32 %0, %8\n\tv_accvgpr_read_b32 %1, %9\n\tv_accvgpr_read_b32 %2, %10\n\tv_accvgpr_read_b32 %3, %11\n\t"
+                 "v_accvgpr_read_b32 %4, %12\n\tv_accvgpr_read_b32 %5, %13\n\tv_accvgpr_read_b32 %6, %14\n\tv_accvgpr_read_b32 %7, %15"
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
+                 : "a"(i0), "a"(i1), "a"(i2), "a"(i3), "a"(i4), "a"(i5), "a"(i6), "a"(i7));
+    asm volatile("v_accvgpr_read_b32 %0, %8\n\tv_accvgpr_read_b32 %1, %9\n\tv_accvgpr_read_b32 %2, %10\n\tv_accvgpr_read_b32 %3, %11\n\t"
+                 "v_accvgpr_read_b32 %4, %12\n\tv_accvgpr_read_b32 %5, %13\n\tv_accvgpr_read_b32 %6, %14\n\tv_accvgpr_read_b32 %7, %15"
+                 : "=&v"(o[8]), "=&v"(o[9]), "=&v"(o[10]), "=&v"(o[11]), "=&v"(o[12]), "=&v"(o[13]), "=&v"(o[14]), "=&v"(o[15])
+                 : "a"(i8), "a"(i9), "a"(i10), "a"(i11), "a"(i12), "a"(i13), "a"(i14), "a"(i15));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dst[r] = o[r];
 }
-__device__ __forceinline__ void acc_read_fence() { asm volatile("s_nop 15\n\ts_nop 15"); }
 
 // PIPE_D: upper bound of the streaming kernel's ring depths (its run-ahead over-reads at most that many
 // tiles: every tiled buffer carries PIPE_D tiles of slack).  The actual padding quanta are per rank class

@@ -83,6 +83,23 @@ __device__ __forceinline__ void split8_bf16(const float* v, u32x4v& hi, u32x4v& 
     lo = u32x4v{l8[0] | ((unsigned)l8[1] << 16), l8[2] | ((unsigned)l8[3] << 16), l8[4] | ((unsigned)l8[5] << 16), l8[6] | ((unsigned)l8[7] << 16)};
 }
 
+// 8 fp32 values -> NT bf16 parts as packed MFMA fragments: part 0 = bf16(v), part p = bf16(v - part 0 - ... - part p-1).  NT = 2
+// is split8_bf16; NT = 3 carries all 24 significant bits of an fp32 value (8 per part, the signs of the residuals give the rest).
+template <int NT>
+__device__ __forceinline__ void split8_parts(const float* v, u32x4v (&part)[NT]) {
+    float r[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = v[e];
+#pragma unroll
+    for (int p = 0; p < NT; ++p) {
+        unsigned short b[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { b[e] = f2bf(r[e]); r[e] -= bf2f(b[e]); }
+        part[p] = u32x4v{b[0] | ((unsigned)b[1] << 16), b[2] | ((unsigned)b[3] << 16), b[4] | ((unsigned)b[5] << 16), b[6] | ((unsigned)b[7] << 16)};
+    }
+}
+
+constexpr int SIGMA_NT = 3;      // bf16 parts per operand of the H <= 64 tile body's product (post_gram_tile_regs, load_sigma_table)
 constexpr int TB_LD = 33;
 template <bool RHO>
 __device__ __forceinline__ float tile_dot_qb(const float (&q)[16], const f32x16& b, float* tb, int lane) {
@@ -434,7 +451,7 @@ __global__ __launch_bounds__(256) void untile_factor_kernel(const uint4* __restr
 // BSIDE = true: the B update (delta-Gram against the previous factor rows pv, tr(B'YA)); false: the A update (label mask
 // of src/vbmf.jl:101, no delta-Gram, no trace).
 template <int MODE, int NH, bool BSIDE = true>
-__device__ __forceinline__ void post_gram_tile_regs(const f32x16 (&q)[NH], const float* stab /* LDS: S[Hp][Hp] */, int xt,
+__device__ __forceinline__ void post_gram_tile_regs(const f32x16 (&q)[NH], const float* stab /* LDS: load_sigma_table's image */, int xt,
                                                     float* __restrict__ Fac, const float* __restrict__ Prev,
                                                     uint4* __restrict__ Ft, int lane,
                                                     f32x16 (&G)[NH * (NH + 1) / 2], f32x16 (&D)[NH * (NH + 1) / 2],
@@ -449,19 +466,48 @@ __device__ __forceinline__ void post_gram_tile_regs(const f32x16 (&q)[NH], const
     for (int h = 0; h < NH; ++h)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[h][r] = 0.f;
-    // exact-f32 MFMA in every mode.  (A three-term bf16 product hi*hi + hi*lo + lo*hi -- 24 MFMAs of 32 cycles instead of 64 of
-    // 64 -- was built and measured: 9 us off the pass at 100k x 10k, but each term then carries 2^-17 instead of 2^-24 and
-    // B = Q * inv(K_B) cancels by the condition number of K_B: BHat off by 5e-4 .. 2.6e-3 on rank-deficient data
-    // (profiles/r02_e_three_term_product.txt).  Parity first: reverted.)
+    // f32 mode: exact-f32 MFMA, the table as plain fp32 in LDS.  bf16 factor modes: the SIX-TERM bf16 product of post_frag2_kernel --
+    // product and table split into three bf16 parts each (together all 24 significant bits of the fp32 values), the products with
+    // part indices i + j <= 2 kept: what is dropped is 2^-24 relative, an fp32 rounding.  48 MFMAs of 32 cycles per 32-row tile at
+    // H = 64 instead of 64 of 64.  (The THREE-term product hi*hi + hi*lo + lo*hi -- 2^-17 per term -- was built first and
+    // rejected: B = Q * inv(K_B) cancels by the condition number of K_B, BHat off by 5e-4 .. 2.6e-3 on rank-deficient data,
+    // profiles/r02_e_three_term_product.txt.)  The table's fragments come pre-split from LDS (load_sigma_frags), in order of use.
+    if constexpr (MODE == MODE_F32) {
 #pragma unroll
-    for (int hin = 0; hin < NH; ++hin)
+        for (int hin = 0; hin < NH; ++hin)
 #pragma unroll
-        for (int t = 0; t < 16; ++t)
+            for (int t = 0; t < 16; ++t)
 #pragma unroll
-            for (int h = 0; h < NH; ++h) {
-                const float a = q[hin][t];
-                acc[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, stab[(hin * 32 + rho(t, half)) * Hp + h * 32 + c], acc[h], 0, 0, 0);
+                for (int h = 0; h < NH; ++h) {
+                    const float a = q[hin][t];
+                    acc[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, stab[(hin * 32 + rho(t, half)) * Hp + h * 32 + c], acc[h], 0, 0, 0);
+                }
+    } else {
+        constexpr int NT = SIGMA_NT;
+        const u32x4v* sf = reinterpret_cast<const u32x4v*>(stab);
+#pragma unroll
+        for (int hin = 0; hin < NH; ++hin)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = q[hin][8 * s2 + e];
+                u32x4v ap[NT];
+                split8_parts<NT>(v, ap);
+#pragma unroll
+                for (int h = 0; h < NH; ++h) {
+                    const int combo = (hin * 2 + s2) * NH + h;
+                    u32x4v bp[NT];
+#pragma unroll
+                    for (int p = 0; p < NT; ++p) bp[p] = sf[(combo * NT + p) * 64 + lane];
+#pragma unroll
+                    for (int pa = 0; pa < NT; ++pa)
+#pragma unroll
+                        for (int pb = 0; pa + pb < NT; ++pb)
+                            acc[h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ap[pa]), __builtin_bit_cast(bf16x8, bp[pb]), acc[h], 0, 0, 0);
+                }
             }
+    }
     // In the bf16 modes the new tile IS hi + lo, and its operand fragments (lane = column, 8 consecutive k per lane) are
     // both operands of the bf16 MFMA with the row index as k: F'F = hi'hi + hi'lo + lo'hi + lo'lo, every product exact,
     // at 1/8 of the exact-f32 MFMA time.  The delta d = old - new is re-split into hi + lo the same way (2^-17 on d).
@@ -553,13 +599,33 @@ __device__ __forceinline__ void post_gram_tile_regs(const f32x16 (&q)[NH], const
     }
 }
 
-// The Sigma / sigma2 table of post_gram_tile_regs into the workgroup's LDS (4 Hp^2 bytes), by all 256 threads, 16-byte loads.
-// The caller barriers.
+// The Sigma / sigma2 table of post_gram_tile_regs into the workgroup's LDS, by all 256 threads.  The caller barriers.
+//   f32 mode:          the plain fp32 table (4 Hp^2 bytes, 16-byte loads)
+//   bf16 factor modes: pre-split into SIGMA_NT bf16 parts as MFMA B-operand fragments in order of use,
+//                      [(hin, s2, h)][part][lane] (1 KiB each: 24 KiB at H = 64), read back conflict-free with ds_read_b128
+template <int MODE, int NH> constexpr int sigma_lds_floats() {
+    return MODE == MODE_F32 ? NH * 32 * NH * 32 : NH * 2 * NH * SIGMA_NT * 256;
+}
 template <int MODE, int NH>
 __device__ __forceinline__ void load_sigma_table(float* stab, const float* __restrict__ S) {
     constexpr int Hp = NH * 32;
-    for (int i = threadIdx.x; i < Hp * Hp / 4; i += 256)
-        reinterpret_cast<float4*>(stab)[i] = reinterpret_cast<const float4*>(S)[i];
+    if constexpr (MODE == MODE_F32) {
+        for (int i = threadIdx.x; i < Hp * Hp / 4; i += 256)
+            reinterpret_cast<float4*>(stab)[i] = reinterpret_cast<const float4*>(S)[i];
+    } else {
+        u32x4v* sf = reinterpret_cast<u32x4v*>(stab);
+        for (int w = threadIdx.x; w < NH * 2 * NH * 64; w += 256) {
+            const int ln = w & 63, combo = w >> 6;
+            const int h = combo % NH, s2 = (combo / NH) & 1, hin = combo / (2 * NH);
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = S[(long long)(hin * 32 + rho(8 * s2 + e, ln >> 5)) * Hp + h * 32 + (ln & 31)];
+            u32x4v part[SIGMA_NT];
+            split8_parts<SIGMA_NT>(v, part);
+#pragma unroll
+            for (int p = 0; p < SIGMA_NT; ++p) sf[(combo * SIGMA_NT + p) * 64 + ln] = part[p];
+        }
+    }
 }
 
 // The Sigma / sigma2 table as pre-split bf16 hi / lo MFMA fragments [(hin, s2, h)][hi | lo][lane] for post_frag_kernel's
@@ -598,20 +664,6 @@ __global__ __launch_bounds__(256) void split_table_kernel(const float* __restric
 //     of 32 cycles per 32 x 32 x 32 block where the exact-f32 MFMA needs 16 of 64.  (NT = 2, three products, is the round-1
 //     form: each product term then carries 2^-17, which B = Q inv(K_B) amplifies by cond(K_B).)
 // BSIDE = false: the A update (label mask, no delta tiles, no trace).
-template <int NT>
-__device__ __forceinline__ void split8_parts(const float* v, u32x4v (&part)[NT]) {
-    float r[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) r[e] = v[e];
-#pragma unroll
-    for (int p = 0; p < NT; ++p) {
-        unsigned short b[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { b[e] = f2bf(r[e]); r[e] -= bf2f(b[e]); }
-        part[p] = u32x4v{b[0] | ((unsigned)b[1] << 16), b[2] | ((unsigned)b[3] << 16), b[4] | ((unsigned)b[5] << 16), b[6] | ((unsigned)b[7] << 16)};
-    }
-}
-
 // The Sigma / sigma2 table as pre-split bf16 MFMA fragments in order of use: [(hin, s2, h)][part < NT][lane] (1 KiB each)
 template <int NH, int NT>
 __global__ __launch_bounds__(256) void split_table_parts_kernel(const float* __restrict__ S, uint4* __restrict__ Sf,
@@ -734,7 +786,6 @@ __global__ __launch_bounds__(256) void post_frag2_kernel(const float4* __restric
     //  blocks' row pointers live across the main loop and push its operand rings into scratch)
     int lane_e = lane;
     asm volatile("" : "+v"(lane_e));
-    acc_read_fence();                                        // the last MFMA's result is read below by hand-placed AGPR reads
     const int c = lane_e & 31, half = lane_e >> 5;
     double tr = 0.0;
     float* tbw = tbuf[wib];
@@ -776,13 +827,9 @@ __global__ __launch_bounds__(256) void post_frag2_kernel(const float4* __restric
 #pragma unroll
         for (int u = 0; u < 4; ++u) qc4[u] = qn[u];
         if (b + 1 < NB) request(b + 1);
-        // (the tile is taken out of the accumulation registers HERE: common.hpp, acc_read)
+        // (the tile is taken out of the accumulation registers HERE: common.hpp, acc_read_tile)
         f32x16 a;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float src = acc[i][h][r];
-            a[r] = acc_read(src);
-        }
+        acc_read_tile(acc[i][h], a);
         if constexpr (!BSIDE) {
             if (mask != nullptr && hcol >= hmask_start) {
 #pragma unroll
@@ -844,7 +891,7 @@ __global__ __launch_bounds__(256) void post_gram2_kernel(const float* __restrict
     constexpr int NPAIR = NH * (NH + 1) / 2;
     __shared__ float fold[2 * NPAIR * 16 * 64];
     __shared__ float tbuf[4][32 * TB_LD];
-    __shared__ __attribute__((aligned(16))) float stab[Hp * Hp];
+    __shared__ __attribute__((aligned(16))) float stab[sigma_lds_floats<MODE, NH>()];
     const int stopped = stop ? __hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;

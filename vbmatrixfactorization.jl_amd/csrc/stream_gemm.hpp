@@ -269,9 +269,10 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const uint4* __restric
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
-        // the SigmaB / sigma2 table goes to LDS once per workgroup (16-byte loads) and is read from there as the MFMA's B
-        // operand, row rho(t, half) for step t: as 64 registers per lane it pushed the tile body over the register file
-        __shared__ __attribute__((aligned(16))) float stab[Hp * Hp];
+        // the SigmaB / sigma2 table goes to LDS once per workgroup and is read from there as the MFMA's B operand (bf16 factor
+        // modes: pre-split into three bf16 parts, post_kernels.hpp load_sigma_table): as registers it pushed the tile body
+        // over the register file
+        __shared__ __attribute__((aligned(16))) float stab[sigma_lds_floats<MODE, NH>()];
         load_sigma_table<MODE, NH>(stab, epi.S);
         __syncthreads();
         const unsigned long long e1 = wall_clock64();
@@ -299,7 +300,11 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const uint4* __restric
 #pragma unroll
                     for (int h = 0; h < NH; ++h) read_factor_tiles<MODE, NH>(epi.Ft, pvn[h], t0 + i + 1, h, lane);
                 }
-                post_gram_tile_regs<MODE, NH>(acc[i], stab, t0 + i, epi.Fac, epi.Prev, epi.Ft, lane, G, D, pvc,
+                // (this tile's product registers leave the AGPR file here, by explicit reads: common.hpp, acc_read_tile)
+                f32x16 qv[NH];
+#pragma unroll
+                for (int h = 0; h < NH; ++h) acc_read_tile(acc[i][h], qv[h]);
+                post_gram_tile_regs<MODE, NH>(qv, stab, t0 + i, epi.Fac, epi.Prev, epi.Ft, lane, G, D, pvc,
                                               epi.store_fac, tbuf[wib], trd);
             }
 #else
@@ -341,42 +346,33 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const uint4* __restric
         // Fragment-major product for the H >= 128 post kernel: tile (x tile, h tile) is 64 lanes x 16 registers, each lane's
         // registers contiguous -- four 16-byte stores per tile here and four 16-byte loads there, instead of sixteen 4-byte
         // row accesses on both sides (the consumer takes register r as the operand of MFMA step r: post_frag_kernel).
-        // (H >= 128: the accumulators leave the AGPR file by explicit reads, tile by tile -- common.hpp, acc_read)
+        // (H >= 128: the accumulators leave the AGPR file by explicit reads, tile by tile -- common.hpp, acc_read_tile)
         float4* o4 = reinterpret_cast<float4*>(Out + (long long)split * (NH * 32) * ldOut);
-        if constexpr (FINE) acc_read_fence();
 #pragma unroll
         for (int i = 0; i < NXW_; ++i)
 #pragma unroll
             for (int h = 0; h < NH; ++h) {
                 float4* t = o4 + (((long long)(xg * NXW_ + i) * NH + h) * 64 + lane) * 4;
+                f32x16 a;
+                if constexpr (FINE) acc_read_tile(acc[i][h], a);
+                else a = acc[i][h];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if constexpr (FINE) {
-                        const float a0 = acc[i][h][4 * q], a1 = acc[i][h][4 * q + 1], a2 = acc[i][h][4 * q + 2], a3 = acc[i][h][4 * q + 3];
-                        t[q] = float4{acc_read(a0), acc_read(a1), acc_read(a2), acc_read(a3)};
-                    } else {
-                        t[q] = float4{acc[i][h][4 * q], acc[i][h][4 * q + 1], acc[i][h][4 * q + 2], acc[i][h][4 * q + 3]};
-                    }
-                }
+                for (int q = 0; q < 4; ++q) t[q] = float4{a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
             }
     } else {
         const int c = lane & 31, half = lane >> 5;
         float* o = Out + (long long)split * (NH * 32) * ldOut;
-        if constexpr (FINE) acc_read_fence();
 #pragma unroll
         for (int i = 0; i < NXW_; ++i) {
             const long long x = (long long)(xg * NXW_ + i) * 32 + c;
 #pragma unroll
-            for (int h = 0; h < NH; ++h)
+            for (int h = 0; h < NH; ++h) {
+                f32x16 a;
+                if constexpr (FINE) acc_read_tile(acc[i][h], a);
+                else a = acc[i][h];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    if constexpr (FINE) {
-                        const float a = acc[i][h][r];
-                        o[(long long)(h * 32 + rho(r, half)) * ldOut + x] = acc_read(a);
-                    } else {
-                        o[(long long)(h * 32 + rho(r, half)) * ldOut + x] = acc[i][h][r];
-                    }
-                }
+                for (int r = 0; r < 16; ++r) o[(long long)(h * 32 + rho(r, half)) * ldOut + x] = a[r];
+            }
         }
     }
 }

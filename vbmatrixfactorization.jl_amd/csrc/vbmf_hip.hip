@@ -141,6 +141,14 @@ struct vbmf_ctx {
 // the collective code path runs whenever a communicator is attached (also a 1-rank one: used to test it)
 static bool sharded(const vbmf_ctx* c) { return c->comm_ready; }
 
+// Host <-> device copies of the set-up and read-back paths: on the context's OWN stream and waited for there.  (A plain
+// hipMemcpy runs on the null stream, which the context's non-blocking streams are not ordered against -- neither the copy
+// after the kernels that produce its source, nor the kernels that consume its destination after the copy.)
+static hipError_t memcpy_sync(vbmf_ctx* c, void* dst, const void* src, size_t n, hipMemcpyKind kind) {
+    const hipError_t e = hipMemcpyAsync(dst, src, n, kind, c->stream);
+    return e != hipSuccess ? e : hipStreamSynchronize(c->stream);
+}
+
 // ------------------------------------------------------------------------------------------------
 #define FAIL(ctx, code, ...)                                   \
     do {                                                       \
@@ -917,7 +925,7 @@ static int check_device_err(vbmf_ctx* c) {
     if (c->ints_host[I_ERR]) {
         const int e = c->ints_host[I_ERR];
         int zero = 0;
-        hipMemcpy(c->ints + I_ERR, &zero, sizeof(int), hipMemcpyHostToDevice);
+        memcpy_sync(c, c->ints + I_ERR, &zero, sizeof(int), hipMemcpyHostToDevice);
         return device_err_status(c, e);
     }
     return VBMF_OK;
@@ -1263,6 +1271,7 @@ int vbmf_preprocess_open(vbmf_prep** out, int device, const double* Y, int64_t L
     p->L_used = (int64_t)p->rows_host.size();
     if (hipMalloc((void**)&p->rows, std::max<size_t>(8, (size_t)p->L_used * 8)) != hipSuccess) return bail("allocation failed");
     if (p->L_used && hipMemcpy(p->rows, p->rows_host.data(), (size_t)p->L_used * 8, hipMemcpyHostToDevice) != hipSuccess) return bail("upload failed");
+    hipDeviceSynchronize();                         // (null-stream work above; the context that consumes p runs on its own stream)
     hipFree(part); hipFree(keep); hipFree(rowsum);
     if (L_used) *L_used = p->L_used;
     *out = p;
@@ -1388,7 +1397,7 @@ static int upload_small(vbmf_ctx* c, const double* srcHxH, long long off, bool m
     } else {
         for (int64_t i = 0; i < c->H; ++i) buf[i] = srcHxH[i];
     }
-    HIPCHK(c, hipMemcpy(c->st + off, buf.data(), buf.size() * 8, hipMemcpyHostToDevice));
+    HIPCHK(c, memcpy_sync(c, c->st + off, buf.data(), buf.size() * 8, hipMemcpyHostToDevice));
     return VBMF_OK;
 }
 
@@ -1412,13 +1421,13 @@ int vbmf_set_state(vbmf_ctx* c, const double* AHat, int64_t ldA, const double* B
     TRY(upload_small(c, SigmaB, c->lay.SB(), true));
     TRY(upload_small(c, CA_diag, c->lay.ca(), false));
     TRY(upload_small(c, CB_diag, c->lay.cb(), false));
-    HIPCHK(c, hipMemcpy(c->st + c->lay.scal() + S_SIGMA2, &sigma2, 8, hipMemcpyHostToDevice));
+    HIPCHK(c, memcpy_sync(c, c->st + c->lay.scal() + S_SIGMA2, &sigma2, 8, hipMemcpyHostToDevice));
     std::vector<unsigned char> mk((size_t)c->Mp, 0);
     for (int64_t i = 0; i < nlabels; ++i) {
         if (labels0[i] < 0 || labels0[i] >= c->M) FAIL(c, VBMF_ERR_INVALID, "vbmf_set_state: label %lld out of range", (long long)labels0[i]);
         mk[(size_t)labels0[i]] = 1;
     }
-    HIPCHK(c, hipMemcpy(c->mask, mk.data(), mk.size(), hipMemcpyHostToDevice));
+    HIPCHK(c, memcpy_sync(c, c->mask, mk.data(), mk.size(), hipMemcpyHostToDevice));
     c->H1 = H1;
     c->has_mask = (nlabels > 0 && H1 > 0);
     TRY(launch_retile(c, 0));
@@ -1446,7 +1455,7 @@ int vbmf_get_state(vbmf_ctx* c, double* AHat, int64_t ldA, double* BHat, int64_t
     if (AHat) { if (ldA < c->M) FAIL(c, VBMF_ERR_INVALID, "ldA < M"); TRY(download_factor(c, c->A32, c->M, AHat, ldA)); }
     if (BHat) { if (ldB < c->L) FAIL(c, VBMF_ERR_INVALID, "ldB < L"); TRY(download_factor(c, c->B32[c->bcur], c->L, BHat, ldB)); }
     std::vector<double> buf((size_t)c->lay.total());
-    HIPCHK(c, hipMemcpy(buf.data(), c->st, buf.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, memcpy_sync(c, buf.data(), c->st, buf.size() * 8, hipMemcpyDeviceToHost));
     auto mat = [&](long long off, double* dst) {
         if (!dst) return;
         for (int64_t j = 0; j < c->H; ++j)
@@ -1602,12 +1611,12 @@ int vbmf_run(vbmf_ctx* c, int64_t niter, double eps, int est_covs, int est_var, 
         if (iters_done) *iters_done = done;
         if (d_last && done > 0) *d_last = c->scal_host[S_D];
         if (trace && done > 0) {
-            if (hipMemcpy(trace, trace_dev, (size_t)done * 4 * 8, hipMemcpyDeviceToHost) != hipSuccess) { c->err = "trace copy failed"; rc = VBMF_ERR_HIP; }
+            if (memcpy_sync(c, trace, trace_dev, (size_t)done * 4 * 8, hipMemcpyDeviceToHost) != hipSuccess) { c->err = "trace copy failed"; rc = VBMF_ERR_HIP; }
         }
         if (c->ints_host[I_ERR]) rc = device_err_status(c, c->ints_host[I_ERR]);
     }
     int zero4[4] = {0, 0, 0, 0};
-    hipMemcpy(c->ints, zero4, sizeof zero4, hipMemcpyHostToDevice);
+    memcpy_sync(c, c->ints, zero4, sizeof zero4, hipMemcpyHostToDevice);
     if (trace_dev) hipFree(trace_dev);
     c->gA_valid = c->gB_valid = true;
     c->P_valid = false;
@@ -1736,7 +1745,7 @@ int vbmf_debug_peek(vbmf_ctx* c, int what, uint32_t* out, int64_t nwords, int64_
     }
     if (what == VBMF_PEEK_CHAIN) {
         if (nwords > 16) FAIL(c, VBMF_ERR_INVALID, "vbmf_debug_peek: the chain stamps are 16 words");
-        HIPCHK(c, hipMemcpy(out, c->ints + 8, (size_t)nwords * 4, hipMemcpyDeviceToHost));
+        HIPCHK(c, memcpy_sync(c, out, c->ints + 8, (size_t)nwords * 4, hipMemcpyDeviceToHost));
         return VBMF_OK;
     }
     const void* base = nullptr;
@@ -1753,7 +1762,7 @@ int vbmf_debug_peek(vbmf_ctx* c, int what, uint32_t* out, int64_t nwords, int64_
         default: FAIL(c, VBMF_ERR_INVALID, "vbmf_debug_peek: unknown buffer");
     }
     if ((size_t)(word_offset + nwords) > words) FAIL(c, VBMF_ERR_INVALID, "vbmf_debug_peek: range exceeds buffer (%zu words)", words);
-    HIPCHK(c, hipMemcpy(out, (const uint32_t*)base + word_offset, (size_t)nwords * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, memcpy_sync(c, out, (const uint32_t*)base + word_offset, (size_t)nwords * 4, hipMemcpyDeviceToHost));
     return VBMF_OK;
 }
 
@@ -2045,19 +2054,19 @@ int vbmf_sparse_set_state(vbmf_ctx* c, const double* ATVecHat, const double* dia
     TRY(upload_small(c, CB, c->lay.cb(), false));
     TRY(upload_small(c, delta, c->lay.ca(), false));
     double sc[32];
-    HIPCHK(c, hipMemcpy(sc, c->st + c->lay.scal(), sizeof sc, hipMemcpyDeviceToHost));
+    HIPCHK(c, memcpy_sync(c, sc, c->st + c->lay.scal(), sizeof sc, hipMemcpyDeviceToHost));
     sc[S_SIGMA2] = sigmaHat; sc[S_ZETA] = zeta; sc[S_ALPHA] = c->alpha; sc[S_GAMMA] = c->gamma_; sc[S_ETA] = c->eta;
     sc[S_BETA0] = hyper->beta0; sc[S_DELTA0] = hyper->delta0; sc[S_ZETA0] = hyper->zeta0;
     // two-group model: both groups start from (alpha0, beta0) and H0 = H until vbmf_dual_set_priors says otherwise
     for (int g = 0; g < 3; ++g) { sc[S_GPRI + 2 * g] = hyper->alpha0; sc[S_GPRI + 2 * g + 1] = hyper->beta0; sc[S_GPOST + g] = hyper->alpha0 + 0.5; }
     if (c->dual) { c->H0 = c->H; c->M0 = c->M; }
-    HIPCHK(c, hipMemcpy(c->st + c->lay.scal(), sc, sizeof sc, hipMemcpyHostToDevice));
+    HIPCHK(c, memcpy_sync(c, c->st + c->lay.scal(), sc, sizeof sc, hipMemcpyHostToDevice));
     std::vector<unsigned char> mk((size_t)c->Mp, 0);
     for (int64_t i = 0; i < nlabels; ++i) {
         if (labels0[i] < 0 || labels0[i] >= c->M) FAIL(c, VBMF_ERR_INVALID, "label out of range");
         mk[(size_t)labels0[i]] = 1;
     }
-    HIPCHK(c, hipMemcpy(c->mask, mk.data(), mk.size(), hipMemcpyHostToDevice));
+    HIPCHK(c, memcpy_sync(c, c->mask, mk.data(), mk.size(), hipMemcpyHostToDevice));
     c->H1 = H1;
     c->has_mask = (nlabels > 0 && H1 > 0);
     TRY(launch_retile(c, 0));
@@ -2091,7 +2100,7 @@ int vbmf_sparse_get_state(vbmf_ctx* c, double* ATVecHat, double* diagSigmaATVec,
     if (beta) TRY(download_vec(c, c->beta32, beta));
     if (BHat) { if (ldB < c->L) FAIL(c, VBMF_ERR_INVALID, "ldB < L"); TRY(download_factor(c, c->B32[c->bcur], c->L, BHat, ldB)); }
     std::vector<double> buf((size_t)c->lay.total());
-    HIPCHK(c, hipMemcpy(buf.data(), c->st, buf.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, memcpy_sync(c, buf.data(), c->st, buf.size() * 8, hipMemcpyDeviceToHost));
     for (int64_t h = 0; h < c->H; ++h) {
         if (SigmaA_diag) SigmaA_diag[h] = buf[(size_t)c->lay.SA() + (size_t)h * c->Hp + h];
         if (CB) CB[h] = buf[(size_t)c->lay.cb() + h];
@@ -2211,8 +2220,8 @@ static int sparse_run_impl(vbmf_ctx* c, int64_t niter, double eps, int est_cb, i
     hipStreamSynchronize(c->side);
     hipStreamSynchronize(c->stream);
     if (rc == VBMF_OK) {
-        hipError_t e = hipMemcpy(c->ints_host, c->ints, 4 * sizeof(int), hipMemcpyDeviceToHost);
-        if (e == hipSuccess) e = hipMemcpy(c->scal_host, c->st + c->lay.scal(), 32 * 8, hipMemcpyDeviceToHost);
+        hipError_t e = memcpy_sync(c, c->ints_host, c->ints, 4 * sizeof(int), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = memcpy_sync(c, c->scal_host, c->st + c->lay.scal(), 32 * 8, hipMemcpyDeviceToHost);
         if (e != hipSuccess) { c->err = "sparse run readback failed"; rc = VBMF_ERR_HIP; }
     }
     if (rc == VBMF_OK) {
@@ -2221,11 +2230,11 @@ static int sparse_run_impl(vbmf_ctx* c, int64_t niter, double eps, int est_cb, i
         rc = rebuild_B32_if_stale(c);
         if (iters_done) *iters_done = done;
         if (d_last && done > 0) *d_last = c->scal_host[S_D];
-        if (rc == VBMF_OK && trace && done > 0 && hipMemcpy(trace, trace_dev, (size_t)done * 4 * 8, hipMemcpyDeviceToHost) != hipSuccess) { c->err = "trace copy failed"; rc = VBMF_ERR_HIP; }
+        if (rc == VBMF_OK && trace && done > 0 && memcpy_sync(c, trace, trace_dev, (size_t)done * 4 * 8, hipMemcpyDeviceToHost) != hipSuccess) { c->err = "trace copy failed"; rc = VBMF_ERR_HIP; }
         if (c->ints_host[I_ERR]) { c->err = "non-positive or non-finite pivot while inverting the posterior precision of B"; rc = VBMF_ERR_NUMERIC; }
     }
     int zero4[4] = {0, 0, 0, 0};
-    hipMemcpy(c->ints, zero4, sizeof zero4, hipMemcpyHostToDevice);
+    memcpy_sync(c, c->ints, zero4, sizeof zero4, hipMemcpyHostToDevice);
     if (trace_dev) hipFree(trace_dev);
     c->gA_valid = c->gB_valid = true;
     c->P_valid = false;
@@ -2275,7 +2284,7 @@ int vbmf_sparse_get_SigmaA(vbmf_ctx* c, double* SigmaA) {
     HIPCHK(c, hipSetDevice(c->o.device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     std::vector<double> buf((size_t)c->Hp * c->Hp);
-    HIPCHK(c, hipMemcpy(buf.data(), c->st + c->lay.SA(), buf.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, memcpy_sync(c, buf.data(), c->st + c->lay.SA(), buf.size() * 8, hipMemcpyDeviceToHost));
     for (int64_t j = 0; j < c->H; ++j)
         for (int64_t i = 0; i < c->H; ++i) SigmaA[i + j * c->H] = buf[(size_t)i * c->Hp + j];
     return VBMF_OK;
@@ -2291,7 +2300,7 @@ static int group_set_priors(vbmf_ctx* c, int64_t H0, int64_t M0, const double* v
         if (!(v9[i] > 0.0) || !std::isfinite(v9[i])) FAIL(c, VBMF_ERR_INVALID, "the Gamma hyper-priors must be positive");
     HIPCHK(c, hipSetDevice(c->o.device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(c->st + c->lay.scal() + S_GPRI, v9, 9 * 8, hipMemcpyHostToDevice));
+    HIPCHK(c, memcpy_sync(c, c->st + c->lay.scal() + S_GPRI, v9, 9 * 8, hipMemcpyHostToDevice));
     c->H0 = H0;
     c->M0 = M0;
     return VBMF_OK;
@@ -2313,7 +2322,7 @@ int vbmf_dual_get_priors(vbmf_ctx* c, int64_t* H0, double* priors6) {
     if (H0) *H0 = c->H0;
     if (priors6) {
         double v[9];
-        HIPCHK(c, hipMemcpy(v, c->st + c->lay.scal() + S_GPRI, sizeof v, hipMemcpyDeviceToHost));
+        HIPCHK(c, memcpy_sync(c, v, c->st + c->lay.scal() + S_GPRI, sizeof v, hipMemcpyDeviceToHost));
         priors6[0] = v[0]; priors6[1] = v[1]; priors6[2] = v[2]; priors6[3] = v[3]; priors6[4] = v[6]; priors6[5] = v[7];
     }
     return VBMF_OK;
@@ -2339,7 +2348,7 @@ int vbmf_trial_get_priors(vbmf_ctx* c, int64_t* H0, int64_t* M0, double* priors9
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (H0) *H0 = c->H0;
     if (M0) *M0 = c->M0;
-    if (priors9) HIPCHK(c, hipMemcpy(priors9, c->st + c->lay.scal() + S_GPRI, 9 * 8, hipMemcpyDeviceToHost));
+    if (priors9) HIPCHK(c, memcpy_sync(c, priors9, c->st + c->lay.scal() + S_GPRI, 9 * 8, hipMemcpyDeviceToHost));
     return VBMF_OK;
 }
 
@@ -2360,10 +2369,10 @@ int vbmf_sparse_set_noise_rows(vbmf_ctx* c, const double* sigmaVecHat, const dou
     double mean = 0.0;
     for (int64_t l = 0; l < c->L; ++l) { s32[(size_t)l] = (float)sigmaVecHat[l]; mean += sigmaVecHat[l]; }
     mean /= (double)c->Lg;                                   // this rank's share of the mean over ALL rows
-    HIPCHK(c, hipMemcpy(c->sigv, sigmaVecHat, (size_t)c->L * 8, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->zetav, zetaVec, (size_t)c->L * 8, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->sig32, s32.data(), (size_t)c->Lp * 4, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->st + c->lay.scal() + S_SIGMA2, &mean, 8, hipMemcpyHostToDevice));
+    HIPCHK(c, memcpy_sync(c, c->sigv, sigmaVecHat, (size_t)c->L * 8, hipMemcpyHostToDevice));
+    HIPCHK(c, memcpy_sync(c, c->zetav, zetaVec, (size_t)c->L * 8, hipMemcpyHostToDevice));
+    HIPCHK(c, memcpy_sync(c, c->sig32, s32.data(), (size_t)c->Lp * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, memcpy_sync(c, c->st + c->lay.scal() + S_SIGMA2, &mean, 8, hipMemcpyHostToDevice));
     c->etaVec = etaVec;
     c->have_noise = true;
     c->noise_mean_reduced = false;
@@ -2375,8 +2384,8 @@ int vbmf_sparse_get_noise_rows(vbmf_ctx* c, double* sigmaVecHat, double* zetaVec
     if (!c->diagvar || !c->have_noise) FAIL(c, VBMF_ERR_INVALID, "no row noise state");
     HIPCHK(c, hipSetDevice(c->o.device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (sigmaVecHat) HIPCHK(c, hipMemcpy(sigmaVecHat, c->sigv, (size_t)c->L * 8, hipMemcpyDeviceToHost));
-    if (zetaVec) HIPCHK(c, hipMemcpy(zetaVec, c->zetav, (size_t)c->L * 8, hipMemcpyDeviceToHost));
+    if (sigmaVecHat) HIPCHK(c, memcpy_sync(c, sigmaVecHat, c->sigv, (size_t)c->L * 8, hipMemcpyDeviceToHost));
+    if (zetaVec) HIPCHK(c, memcpy_sync(c, zetaVec, c->zetav, (size_t)c->L * 8, hipMemcpyDeviceToHost));
     return VBMF_OK;
 }
 
@@ -2400,8 +2409,8 @@ static int sparse_lower_bound_impl(vbmf_ctx* c, int clamp, double trim, double* 
     HIPCHK(c, hipGetLastError());
     std::vector<double> part((size_t)nb * LB_NS), buf((size_t)c->lay.total());
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(part.data(), c->ypart, part.size() * 8, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(buf.data(), c->st, buf.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, memcpy_sync(c, part.data(), c->ypart, part.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, memcpy_sync(c, buf.data(), c->st, buf.size() * 8, hipMemcpyDeviceToHost));
     double s_logbeta_g[3] = {0, 0, 0}, s_ca_g[3] = {0, 0, 0}, s_caq = 0, s_logds = 0, n_keep = 0, s_logbeta_keep = 0, s_ca_keep = 0;
     for (int b = 0; b < nb; ++b) {
         for (int g = 0; g < 3; ++g) { s_logbeta_g[g] += part[LB_NS * b + g]; s_ca_g[g] += part[LB_NS * b + 4 + g]; }

@@ -38,16 +38,22 @@ def host_staged_transport(all_reduce_numpy):
     import numpy as np
     hip = C.CDLL("libamdhip64.so")
     hip.hipStreamSynchronize.argtypes = [C.c_void_p]
-    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
 
     def fn(buf, count, is_double, stream):
+        # Both copies go on the LIBRARY's stream and are waited for there.  (A plain hipMemcpy runs on the null stream, which
+        # the library's non-blocking streams are not ordered against, and a host-to-device copy from pageable memory may
+        # return before its DMA has landed: the next kernel on `stream` could then read the buffer too early -- seen as a
+        # once-in-several-runs mismatch of the replicated factor across ranks.)
         a = np.empty(count, dtype=np.float64 if is_double else np.float32)
+        if hip.hipMemcpyAsync(a.ctypes.data, buf, a.nbytes, 2, stream) != 0:      # hipMemcpyDeviceToHost, after the producers
+            return 3
         if hip.hipStreamSynchronize(stream) != 0:
             return 2
-        if hip.hipMemcpy(a.ctypes.data, buf, a.nbytes, 2) != 0:          # hipMemcpyDeviceToHost
-            return 3
         all_reduce_numpy(a)
-        if hip.hipMemcpy(buf, a.ctypes.data, a.nbytes, 1) != 0:          # hipMemcpyHostToDevice
+        if hip.hipMemcpyAsync(buf, a.ctypes.data, a.nbytes, 1, stream) != 0:      # hipMemcpyHostToDevice, before the consumers
             return 4
+        if hip.hipStreamSynchronize(stream) != 0:                                 # (`a` must outlive the copy)
+            return 2
         return 0
     return fn
