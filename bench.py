@@ -139,7 +139,16 @@ def main():
     # per process); torch is plumbing here (rendezvous, barrier, max-over-ranks), never compute
     import torch
     import torch.distributed as dist
-    if world > 1:
+    # VBMF_BENCH_TRANSPORT=host: REHEARSAL of the N > 1 path on a one-GPU box -- every rank on device 0, rendezvous and the
+    # library's all-reduces over gloo through host memory (dist.host_staged_transport).  Exercises this file's own multi-rank
+    # logic (shard arithmetic, barrier, max over ranks, rank-0 JSON) and the library's collective code path; its number is NOT a
+    # measurement of anything (the line says so).  RCCL over xGMI is the only transport of a real run.
+    host_transport = world > 1 and os.environ.get("VBMF_BENCH_TRANSPORT", "") == "host"
+    if world > 1 and host_transport:
+        local_rank = 0
+        torch.cuda.set_device(0)
+        dist.init_process_group(backend="gloo")
+    elif world > 1:
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
@@ -165,7 +174,9 @@ def main():
     ctx = capi.Context(L_loc, M, H, y_dtype=y_dtype, factor_dtype=f_dtype, device=local_rank, nranks=world,
                        rank=rank, L_global=(L_loc if emu else L), row_offset=row0, pass1_splits=a.splits,
                        variant=capi.VBMF_VARIANT_SPARSE_DIAG if sparse else capi.VBMF_VARIANT_BASIC)
-    if world > 1:
+    if host_transport:
+        ctx.comm_set_transport(pkg.dist.host_staged_transport(lambda arr: dist.all_reduce(torch.from_numpy(arr))))
+    elif world > 1:
         uid = [capi.Context.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         ctx.comm_init(uid[0])
@@ -220,7 +231,7 @@ def main():
 
     elapsed = t1 - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if host_transport else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -294,6 +305,9 @@ def main():
         hb = {k: out["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac")}
         out["roofline"].update({k: out["roofline"]["other_roof"][k] for k in ("bound", "achieved", "peak", "unit", "frac")})
         out["roofline"]["other_roof"] = dict(hb, bytes_per_launch=avg_bytes)
+    if host_transport:
+        out["config"]["rehearsal"] = (f"{world} ranks on ONE GPU, all-reduces staged through host memory over gloo "
+                                      "(VBMF_BENCH_TRANSPORT=host): a dry run of the multi-rank code path, NOT a measurement")
     if emu:
         out["config"]["emulation"] = (f"rank 0's share of a {emu}-rank strong-scaling run on one GPU ({L_loc} of {L} rows, "
                                       "1-rank RCCL communicator, L_global = the share): per-rank compute only, no inter-GPU latency")
