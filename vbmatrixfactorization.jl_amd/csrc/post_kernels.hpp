@@ -982,6 +982,7 @@ __global__ __launch_bounds__(1024) void pair_slab_reduce_kernel(const float* __r
     if (outTr != nullptr && blockIdx.x == gridDim.x - 1) fold_wave_dots(trpart, ntr, outTr);
     const int j = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int idx = blockIdx.x * 64 + j;                       // (mat, pair, r, lane) flat, grid = NOUT/64
+    if ((idx / (NPAIR * 1024) ? outD : outG) == nullptr) return;   // (block-uniform: 1024 % 64 == 0) a matrix nobody asked for
     double s = 0.0;
 #pragma unroll 4
     for (int k = g; k < nslab; k += NG) s += (double)slabs[(long long)k * NOUT + idx];
@@ -1301,6 +1302,128 @@ __global__ __launch_bounds__(256) void gram_tiles2_kernel(const uint4* __restric
     else if (wib == 1) gram_tiles_job<NH, NPART, 1>(Ft, Fd, o, t0, t1, lane);
     else if (wib == 2) gram_tiles_job<NH, NPART, 2>(Ft, Fd, o, t0, t1, lane);
     else gram_tiles_job<NH, NPART, 3>(Ft, Fd, o, t0, t1, lane);
+}
+
+// gram_tiles3: gram_tiles2 with the step's fragments SHARED by the workgroup's four waves through LDS.  In gram_tiles2 every wave
+// loads all NPART * NH fragments of a step itself (its pairs span every column tile): 4 x 16 KiB per step and CU through a 32 KiB
+// L1 with three steps in flight -- the waves evict each other's lines and the kernel runs at L2 speed (1.6 us per step at
+// 100k x 256 against 0.55 us of MFMA).  Here each wave fetches a QUARTER of the step (register ring, DR steps of HBM latency),
+// publishes it into one of two LDS stages one step ahead, and all four read the whole step from LDS (ds_read_b128, lane-linear:
+// conflict-free) after ONE raw s_barrier per step.  Stage (s + 1) & 1 is written during step s: it last held step s - 1, which
+// every wave finished reading before the barrier that ended step s - 1.  Same MFMA order per pair as gram_tiles2 (bit-identical).
+template <int NH, int NPART, int W>
+__device__ __forceinline__ void gram_tiles_lds_body(const uint4* __restrict__ Ft, float* __restrict__ o, int t0, int t1, int lane,
+                                                    u32x4v* fl /* LDS: [2][NPART * NH][64] */) {
+    constexpr int Hp = NH * 32;
+    constexpr int NPAIR = NH * (NH + 1) / 2;
+    constexpr int PW = (NPAIR + 3) / 4;
+    constexpr int NF = NPART * NH, NFW = NF / 4;
+    static_assert(NF % 4 == 0, "four waves share the fetch");
+    constexpr int DR = 4;                                        // even: the LDS stage of step s0 + d is d & 1
+    constexpr unsigned STEP_BYTES = (unsigned)NF * 1024u;
+    const int nsteps = 2 * (t1 - t0);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(Ft + (long long)t0 * 2 * NF * 64), 0,
+                                                                        (unsigned)nsteps * STEP_BYTES, 0x00020000);
+    f32x16 G[PW];
+#pragma unroll
+    for (int q = 0; q < PW; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) G[q][r] = 0.f;
+    u32x4v gl[DR][NFW];
+#pragma unroll
+    for (int d = 0; d < DR; ++d) {
+        const int vo = lane * 16 + d * (int)STEP_BYTES;          // (steps past the chunk: out of the descriptor's range -> zeros)
+#pragma unroll
+        for (int j = 0; j < NFW; ++j) gl[d][j] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, (W * NFW + j) * 1024, 0);
+    }
+    // the previous job's last reads of the stages are over (all waves), then step 0 -> stage 0
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < NFW; ++j) fl[(W * NFW + j) * 64 + lane] = gl[0][j];
+    {
+        const int vo = lane * 16 + DR * (int)STEP_BYTES;
+#pragma unroll
+        for (int j = 0; j < NFW; ++j) gl[0][j] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, (W * NFW + j) * 1024, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    for (int s0 = 0; s0 < nsteps; s0 += DR) {
+#pragma unroll
+        for (int d = 0; d < DR; ++d) {
+            const int cur = d & 1, nxt = cur ^ 1, gd = (d + 1) % DR;
+            // publish this wave's quarter of step s0 + d + 1 (fetched DR steps ago), refetch the slot for step s0 + d + 1 + DR
+#pragma unroll
+            for (int j = 0; j < NFW; ++j) fl[(nxt * NF + W * NFW + j) * 64 + lane] = gl[gd][j];
+            const int vo = lane * 16 + (s0 + d + 1 + DR) * (int)STEP_BYTES;
+#pragma unroll
+            for (int j = 0; j < NFW; ++j) gl[gd][j] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, (W * NFW + j) * 1024, 0);
+            // the whole step from LDS, then this wave's pairs
+            u32x4v f[NH][NPART];
+#pragma unroll
+            for (int pa = 0; pa < NPART; ++pa)
+#pragma unroll
+                for (int h = 0; h < NH; ++h) f[h][pa] = fl[(cur * NF + pa * NH + h) * 64 + lane];
+            int p = 0;
+#pragma unroll
+            for (int h1 = 0; h1 < NH; ++h1)
+#pragma unroll
+                for (int h2 = h1; h2 < NH; ++h2, ++p) {
+                    if ((p & 3) != W) continue;              // compile-time after unrolling
+                    const int qq = p >> 2;
+#pragma unroll
+                    for (int pa = 0; pa < NPART; ++pa)
+#pragma unroll
+                        for (int pb = 0; pb < NPART; ++pb)
+                            G[qq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f[h1][pa]),
+                                                                            __builtin_bit_cast(bf16x8, f[h2][pb]), G[qq], 0, 0, 0);
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+    }
+    // pair-slab format (pair_slab_reduce_kernel): [pair][16 registers][64 lanes], the accumulator tile as it stands -- one
+    // coalesced 256-byte row per register, upper-triangular pairs only (the dense [Hp][Hp] slab with both triangles that
+    // gram_tiles2 writes is 1.8x the bytes and its mirrored half goes out as 4-byte stores 1 KiB apart)
+    int lane_e = lane;                                       // (store addresses from an opaque copy: not hoisted over the loop)
+    asm volatile("" : "+v"(lane_e));
+    int p = 0;
+#pragma unroll
+    for (int h1 = 0; h1 < NH; ++h1)
+#pragma unroll
+        for (int h2 = h1; h2 < NH; ++h2, ++p) {
+            if ((p & 3) != W) continue;
+            const int qq = p >> 2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[(p * 16 + r) * 64 + lane_e] = G[qq][r];
+        }
+}
+template <int NH, int NPART, int W>
+__device__ __forceinline__ void gram_tiles_lds_job(const uint4* __restrict__ Ft, const uint4* __restrict__ Fd, float* __restrict__ o,
+                                                   int t0, int t1, int lane, u32x4v* fl) {
+    gram_tiles_lds_body<NH, NPART, W>(Ft, o, t0, t1, lane, fl);
+    if (Fd != nullptr) gram_tiles_lds_body<NH, 2, W>(Fd, o + (NH * (NH + 1) / 2) * 1024, t0, t1, lane, fl);   // (workgroup-uniform)
+}
+template <int NH, int NPART>
+__global__ __launch_bounds__(256) void gram_tiles3_kernel(const uint4* __restrict__ Ft, const uint4* __restrict__ Fd,
+                                                          float* __restrict__ slabs, int XT, int tiles_per_chunk,
+                                                          const int* __restrict__ stop) {
+    constexpr int NPAIR = NH * (NH + 1) / 2;
+    __shared__ __attribute__((aligned(16))) u32x4v fl[2 * 2 * NH * 64];      // two stages of up to 2 NH fragments
+    if (stop && *stop) return;
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int chunk = blockIdx.x;
+    const int t0 = chunk * tiles_per_chunk;
+    const int t1 = min(XT, t0 + tiles_per_chunk);
+    float* o = slabs + (long long)chunk * 2 * NPAIR * 1024;
+    if (wib == 0) gram_tiles_lds_job<NH, NPART, 0>(Ft, Fd, o, t0, t1, lane, fl);
+    else if (wib == 1) gram_tiles_lds_job<NH, NPART, 1>(Ft, Fd, o, t0, t1, lane, fl);
+    else if (wib == 2) gram_tiles_lds_job<NH, NPART, 2>(Ft, Fd, o, t0, t1, lane, fl);
+    else gram_tiles_lds_job<NH, NPART, 3>(Ft, Fd, o, t0, t1, lane, fl);
 }
 
 // out[which][i] = sum_chunk slabs[chunk][which][i]  (fp64).  which in {0: Gram, 1: delta-Gram}.

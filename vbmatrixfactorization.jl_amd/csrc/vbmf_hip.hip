@@ -576,7 +576,9 @@ static int launch_retile(vbmf_ctx* c, int which, bool gated = false) {
 static int gram_tiles_per_chunk(const vbmf_ctx* c, int which) {
     if (c->NH < 4) return c->tiles_per_chunk;
     const int XT = which == 0 ? c->d1.XT : c->d2.XT;
-    return XT >= 2048 ? c->tiles_per_chunk : std::max(4, cdiv(XT, 96));
+    // long side: one round of ~250 workgroups (fp32 factor mode: the dense-slab kernels keep the context-wide value)
+    if (XT >= 2048) return c->mode == MODE_F32 ? c->tiles_per_chunk : std::max(8, cdiv(XT, 250));
+    return std::max(4, cdiv(XT, 96));
 }
 // Gram of A (which=0) or of B with optional delta-Gram against prev (which=1) into the state block.
 static int launch_gram(vbmf_ctx* c, int which, const float* cur, const float* prev, bool gated, int ntr = 0) {
@@ -588,15 +590,17 @@ static int launch_gram(vbmf_ctx* c, int which, const float* cur, const float* pr
     // H >= 128 with a bf16 factor: from the operand tiles with bf16 MFMAs (the tiles of `cur` are current whenever a
     // Gram of it is asked for: every producer of the fp32 factor writes them in the same kernel)
     const bool from_tiles = c->NH >= 4 && c->mode != MODE_F32;
+    bool pair_slabs = false;
     if (from_tiles) {
         const uint4* Ft = which == 0 ? c->FA : c->FB;
         // delta-Gram: a plain tile Gram of the delta tiles the post kernel left (two parts: hi + lo) -- or, without them
         // (f32-free callers that bring their own previous fp32 factor), from `prev` with row gathers
         const bool from_fd = which == 1 && prev != nullptr && c->fd_valid && c->FD != nullptr;
+        pair_slabs = from_fd || prev == nullptr;
 #define GRAM_TILES(NHc_, NPc_)                                                                                               \
     do {                                                                                                                         \
         if (from_fd || prev == nullptr) {                                                                                        \
-            hipLaunchKernelGGL((gram_tiles2_kernel<NHc_, NPc_>), dim3(nchunk), dim3(256), 0, c->stream, Ft,                        \
+            hipLaunchKernelGGL((gram_tiles3_kernel<NHc_, NPc_>), dim3(nchunk), dim3(256), 0, c->stream, Ft,                        \
                                from_fd ? (const uint4*)c->FD : (const uint4*)nullptr, c->gslab, d.XT, tpc, stop);  \
         } else {                                                                                                                 \
             hipLaunchKernelGGL((gram_tiles_kernel<NHc_, NPc_, 0>), dim3(nchunk), dim3(256), 0, c->stream, Ft, prev, c->gslab,      \
@@ -619,8 +623,13 @@ static int launch_gram(vbmf_ctx* c, int which, const float* cur, const float* pr
     double* outG = shard ? c->gtmp : c->st + (which == 0 ? c->lay.GA() : c->lay.GB());
     double* outD = which == 0 ? nullptr : (shard ? c->gtmp + n : c->st + c->lay.GD());
     double* outTr = (which == 1 && ntr > 0) ? (shard ? c->gtmp + 2 * n : c->st + c->lay.GX()) : nullptr;
-    hipLaunchKernelGGL(gram_reduce_kernel, dim3((2 * n + 31) / 32), dim3(256), 0, c->stream, c->gslab, nchunk, n,
-                       outG, outD, stop, c->trpart, ntr, outTr);
+    if (pair_slabs) {                              // gram_tiles3 leaves pair slabs (the H <= 64 kernels' format)
+        if (c->NH == 4) hipLaunchKernelGGL((pair_slab_reduce_kernel<4>), dim3(2 * 10 * 1024 / 64), dim3(1024), 0, c->stream, c->gslab, nchunk, outG, outD, stop, c->trpart, ntr, outTr);
+        else hipLaunchKernelGGL((pair_slab_reduce_kernel<8>), dim3(2 * 36 * 1024 / 64), dim3(1024), 0, c->stream, c->gslab, nchunk, outG, outD, stop, c->trpart, ntr, outTr);
+    } else {
+        hipLaunchKernelGGL(gram_reduce_kernel, dim3((2 * n + 31) / 32), dim3(256), 0, c->stream, c->gslab, nchunk, n,
+                           outG, outD, stop, c->trpart, ntr, outTr);
+    }
     HIPCHK(c, hipGetLastError());
     if (shard) {
         if (!c->comm_ready) FAIL(c, VBMF_ERR_COMM, "nranks > 1 but vbmf_comm_init was not called");
