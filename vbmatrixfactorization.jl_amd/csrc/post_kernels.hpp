@@ -683,7 +683,15 @@ __global__ __launch_bounds__(256) void split_table_parts_kernel(const float* __r
     for (int p = 0; p < NT; ++p) Sf[((long long)combo * NT + p) * 64 + ln] = uint4{part[p][0], part[p][1], part[p][2], part[p][3]};
 }
 
-template <int NH> struct PostFrag2Cfg { static constexpr int NXT = NH >= 8 ? 2 : 4; static constexpr int D = NH >= 8 ? 8 : 4; };
+// row tiles per wave on a LONG side (tuning switches, A/B on the GPU): 256 accumulator registers' worth (one wave per SIMD) or half
+// of it (two waves per SIMD: one wave's epilogue overlaps the other's MFMA loop)
+#ifndef VBMF_POST2_NXT8
+#define VBMF_POST2_NXT8 2
+#endif
+#ifndef VBMF_POST2_NXT4
+#define VBMF_POST2_NXT4 4
+#endif
+template <int NH> struct PostFrag2Cfg { static constexpr int NXT = NH >= 8 ? VBMF_POST2_NXT8 : VBMF_POST2_NXT4; };
 
 // NXT: 32-row tiles per wave (PostFrag2Cfg<NH>::NXT on a long side, 1 on a short one: more workgroups)
 template <int MODE, int NH, int NXT, int NT, bool BSIDE>
@@ -694,7 +702,7 @@ __global__ __launch_bounds__(256) void post_frag2_kernel(const float4* __restric
                                                          uint4* __restrict__ Fd, int store_fac) {
     static_assert(MODE != MODE_F32, "bf16 factor modes only (the fp32 mode keeps post_frag_kernel's exact-f32 MFMA)");
     constexpr int Hp = NH * 32;
-    constexpr int D = PostFrag2Cfg<NH>::D;
+    constexpr int D = (NH >= 8 && NXT >= 2) ? 8 : 4;          // table ring depth (iterations); 4 keeps NXT = 1 under 256 registers
     constexpr int NIT = 2 * NH;                               // table iterations (s2, h) per hin
     static_assert(NIT % D == 0, "ring slot = iteration mod D must not depend on hin");
     __shared__ float tbuf[4][32 * TB_LD];
@@ -814,7 +822,10 @@ __global__ __launch_bounds__(256) void post_frag2_kernel(const float4* __restric
             for (int qd = 0; qd < 4; ++qd) qn[qd] = t4[qd];
         }
     };
-    request(0);
+    // (with half the accumulator registers or fewer, two or more waves run per SIMD and overlap each other's round trips: no
+    //  read-ahead there, it would cost the 32 registers that keep the wave under 128 VGPRs)
+    constexpr bool AHEAD = NXT * NH >= 16;
+    if constexpr (AHEAD) request(0);
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const int i = b / NH, h = b % NH;
@@ -822,11 +833,14 @@ __global__ __launch_bounds__(256) void post_frag2_kernel(const float4* __restric
         if (xt >= XT) break;
         const long long x0 = (long long)xt * 32;
         const int hcol = h * 32 + c;
+        if constexpr (!AHEAD) request(b);
 #pragma unroll
         for (int u = 0; u < 2 * NPART; ++u) oc[u] = on[u];
 #pragma unroll
         for (int u = 0; u < 4; ++u) qc4[u] = qn[u];
-        if (b + 1 < NB) request(b + 1);
+        if constexpr (AHEAD) {
+            if (b + 1 < NB) request(b + 1);
+        }
         // (the tile is taken out of the accumulation registers HERE: common.hpp, acc_read_tile)
         f32x16 a;
         acc_read_tile(acc[i][h], a);
@@ -1196,121 +1210,22 @@ __global__ __launch_bounds__(256) void gram_tiles_kernel(const uint4* __restrict
         }
 }
 
-// gram_tiles2: the tile Gram with its operand fragments PREFETCHED -- gram_tiles_kernel<., ., 0> loaded a 16-row step's
-// fragments, waited, multiplied, and only then asked for the next step: one exposed HBM round trip per step and workgroup
-// (profiles/r02_pmc_mfma_cfg5.json: 13 % MFMA busy; 66 us for the 102 MB of B tiles at 100k x 256, 20 us of HBM time).  Here a
-// DR-deep register ring of steps is refilled in place right after use (buffer loads + sched_group_barrier, as in the streaming
-// kernel); the step offset travels in the VGPR offset, so steps past the chunk's end are out of the descriptor's range and
-// arrive as zeros (they add nothing) -- no remainder loop.  The wave's pair set is a template parameter (straight-line code per
-// wave instead of 36 wave-uniform branches per step).  Gram of `Ft` into slab half 0 and, if given, of the delta tiles `Fd`
-// (two parts) into slab half 1, in ONE launch.  Same slab format and the same MFMA order per pair as gram_tiles_kernel.
-template <int NH, int W> constexpr int gram_pairs_of_wave() {
-    int n = 0, p = 0;
-    for (int h1 = 0; h1 < NH; ++h1)
-        for (int h2 = h1; h2 < NH; ++h2, ++p)
-            if ((p & 3) == W) ++n;
-    return n;
-}
-template <int NH, int NPART, int W>
-__device__ __forceinline__ void gram_tiles_body(const uint4* __restrict__ Ft, float* __restrict__ o, int t0, int t1, int lane) {
-    constexpr int Hp = NH * 32;
-    constexpr int NPAIR = NH * (NH + 1) / 2;
-    constexpr int PW = (NPAIR + 3) / 4;
-    constexpr int DR = NH >= 8 ? 3 : 6;
-    constexpr int NM = gram_pairs_of_wave<NH, W>() * NPART * NPART;
-    constexpr unsigned STEP_BYTES = (unsigned)NPART * NH * 1024u;
-    const int nsteps = 2 * (t1 - t0);
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(Ft + (long long)t0 * 2 * NPART * NH * 64), 0,
-                                                                        (unsigned)nsteps * STEP_BYTES, 0x00020000);
-    f32x16 G[PW];
-#pragma unroll
-    for (int q = 0; q < PW; ++q)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) G[q][r] = 0.f;
-    u32x4v f[DR][NH][NPART];
-#pragma unroll
-    for (int d = 0; d < DR; ++d) {
-        const int vo = lane * 16 + d * (int)STEP_BYTES;
-#pragma unroll
-        for (int pa = 0; pa < NPART; ++pa)
-#pragma unroll
-            for (int h = 0; h < NH; ++h) f[d][h][pa] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, (pa * NH + h) * 1024, 0);
-    }
-    for (int s0 = 0; s0 < nsteps; s0 += DR) {
-#pragma unroll
-        for (int d = 0; d < DR; ++d) {
-            int p = 0;
-#pragma unroll
-            for (int h1 = 0; h1 < NH; ++h1)
-#pragma unroll
-                for (int h2 = h1; h2 < NH; ++h2, ++p) {
-                    if ((p & 3) != W) continue;              // compile-time after unrolling
-                    const int qq = p >> 2;
-#pragma unroll
-                    for (int pa = 0; pa < NPART; ++pa)
-#pragma unroll
-                        for (int pb = 0; pb < NPART; ++pb)
-                            G[qq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f[d][h1][pa]),
-                                                                            __builtin_bit_cast(bf16x8, f[d][h2][pb]), G[qq], 0, 0, 0);
-                }
-            const int vo = lane * 16 + (s0 + d + DR) * (int)STEP_BYTES;
-#pragma unroll
-            for (int pa = 0; pa < NPART; ++pa)
-#pragma unroll
-                for (int h = 0; h < NH; ++h) f[d][h][pa] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, (pa * NH + h) * 1024, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, NH * NPART, 0);
-        }
-    }
-    int lane_e = lane;                                       // (store addresses from an opaque copy: not hoisted over the loop)
-    asm volatile("" : "+v"(lane_e));
-    const int c = lane_e & 31, half = lane_e >> 5;
-    int p = 0;
-#pragma unroll
-    for (int h1 = 0; h1 < NH; ++h1)
-#pragma unroll
-        for (int h2 = h1; h2 < NH; ++h2, ++p) {
-            if ((p & 3) != W) continue;
-            const int qq = p >> 2;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long long i = h1 * 32 + rho(r, half), j = h2 * 32 + c;
-                o[i * Hp + j] = G[qq][r];
-                if (h1 != h2) o[j * Hp + i] = G[qq][r];
-            }
-        }
-}
-template <int NH, int NPART, int W>
-__device__ __forceinline__ void gram_tiles_job(const uint4* __restrict__ Ft, const uint4* __restrict__ Fd, float* __restrict__ o,
-                                               int t0, int t1, int lane) {
-    gram_tiles_body<NH, NPART, W>(Ft, o, t0, t1, lane);
-    if (Fd != nullptr) gram_tiles_body<NH, 2, W>(Fd, o + NH * 32 * NH * 32, t0, t1, lane);
-}
-template <int NH, int NPART>
-__global__ __launch_bounds__(256) void gram_tiles2_kernel(const uint4* __restrict__ Ft, const uint4* __restrict__ Fd,
-                                                          float* __restrict__ slabs, int XT, int tiles_per_chunk,
-                                                          const int* __restrict__ stop) {
-    constexpr int Hp = NH * 32;
-    if (stop && *stop) return;
-    const int lane = threadIdx.x & 63;
-    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int chunk = blockIdx.x;
-    const int t0 = chunk * tiles_per_chunk;
-    const int t1 = min(XT, t0 + tiles_per_chunk);
-    float* o = slabs + (long long)chunk * 2 * Hp * Hp;
-    if (wib == 0) gram_tiles_job<NH, NPART, 0>(Ft, Fd, o, t0, t1, lane);
-    else if (wib == 1) gram_tiles_job<NH, NPART, 1>(Ft, Fd, o, t0, t1, lane);
-    else if (wib == 2) gram_tiles_job<NH, NPART, 2>(Ft, Fd, o, t0, t1, lane);
-    else gram_tiles_job<NH, NPART, 3>(Ft, Fd, o, t0, t1, lane);
-}
-
-// gram_tiles3: gram_tiles2 with the step's fragments SHARED by the workgroup's four waves through LDS.  In gram_tiles2 every wave
-// loads all NPART * NH fragments of a step itself (its pairs span every column tile): 4 x 16 KiB per step and CU through a 32 KiB
-// L1 with three steps in flight -- the waves evict each other's lines and the kernel runs at L2 speed (1.6 us per step at
-// 100k x 256 against 0.55 us of MFMA).  Here each wave fetches a QUARTER of the step (register ring, DR steps of HBM latency),
-// publishes it into one of two LDS stages one step ahead, and all four read the whole step from LDS (ds_read_b128, lane-linear:
-// conflict-free) after ONE raw s_barrier per step.  Stage (s + 1) & 1 is written during step s: it last held step s - 1, which
-// every wave finished reading before the barrier that ended step s - 1.  Same MFMA order per pair as gram_tiles2 (bit-identical).
+// gram_tiles3: the tile Gram of the H >= 128 run loops (bf16 factor modes), Gram of `Ft` and -- in the same launch -- of the
+// delta tiles `Fd`.  What it fixes in gram_tiles_kernel<., ., 0>, in the order it was found (profiles/r02_pmc_mfma_cfg5.json: 13 %
+// MFMA busy; 66 + 62 us for the 2 x 102 MB of tiles at 100k x 256, 20 us of HBM time each):
+//   * one exposed HBM round trip per 16-row step (load, wait, multiply, next load)      -> a DR-deep register ring of steps, refilled
+//     in place right after use (buffer loads; the step offset travels in the VGPR offset, so steps past the chunk's end are out
+//     of the descriptor's range and arrive as zeros: no remainder loop)                                             128 -> 102 us
+//   * 36 wave-uniform branches per step (the wave's pair set as a run-time test)         -> the pair set is a template parameter
+//   * every wave loads all NPART * NH fragments of a step itself (its pairs span every column tile): 4 x 16 KiB per step and CU
+//     through a 32 KiB L1 with several steps in flight -- the waves evict each other's lines                         -> each wave
+//     fetches a QUARTER of the step, publishes it into one of two LDS stages one step ahead, and all four read the whole step
+//     from LDS (ds_read_b128, lane-linear: conflict-free) after ONE raw s_barrier per step.  Stage (s + 1) & 1 is written during
+//     step s: it last held step s - 1, which every wave finished reading before the barrier that ended step s - 1.   102 -> 92 us
+//   * a dense [Hp][Hp] slab with both triangles per chunk, the mirrored half as 4-byte stores 1 KiB apart, 196 chunks on 256 CUs
+//     -> pair slabs (the accumulator tiles as they stand, upper pairs only, coalesced; pair_slab_reduce_kernel expands them) and
+//     one round of ~250 chunks                                                                                       92 -> 68 us
+// Same MFMA order per pair as gram_tiles_kernel.
 template <int NH, int NPART, int W>
 __device__ __forceinline__ void gram_tiles_lds_body(const uint4* __restrict__ Ft, float* __restrict__ o, int t0, int t1, int lane,
                                                     u32x4v* fl /* LDS: [2][NPART * NH][64] */) {
@@ -1386,8 +1301,8 @@ __device__ __forceinline__ void gram_tiles_lds_body(const uint4* __restrict__ Ft
         }
     }
     // pair-slab format (pair_slab_reduce_kernel): [pair][16 registers][64 lanes], the accumulator tile as it stands -- one
-    // coalesced 256-byte row per register, upper-triangular pairs only (the dense [Hp][Hp] slab with both triangles that
-    // gram_tiles2 writes is 1.8x the bytes and its mirrored half goes out as 4-byte stores 1 KiB apart)
+    // coalesced 256-byte row per register, upper-triangular pairs only (the dense [Hp][Hp] slab with both triangles of
+    // gram_tiles_kernel is 1.8x the bytes and its mirrored half goes out as 4-byte stores 1 KiB apart)
     int lane_e = lane;                                       // (store addresses from an opaque copy: not hoisted over the loop)
     asm volatile("" : "+v"(lane_e));
     int p = 0;

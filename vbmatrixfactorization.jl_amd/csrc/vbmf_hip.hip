@@ -477,7 +477,7 @@ static int launch_post_frag(vbmf_ctx* c, int which = 1, const float* In = nullpt
     // row tiles per wave: 256 accumulator registers' worth on the long side; ONE on a short side (the 10k-row A side would
     // otherwise occupy 20 workgroups)
     const bool short_side = d.XT < 2048;
-    const int nxt = short_side ? 1 : (c->NH >= 8 ? 2 : 4);                          // = PostFrag2Cfg<NH>::NXT
+    const int nxt = short_side ? 1 : (c->NH >= 8 ? VBMF_POST2_NXT8 : VBMF_POST2_NXT4);   // = PostFrag2Cfg<NH>::NXT
     const int grid = (cdiv(d.XT, nxt) + 3) / 4;
     double* trp = (which == 1 && !c->diagvar && 4 * grid <= c->trpart_cap) ? c->trpart : nullptr;
     if (which == 1) c->ntr = trp ? 4 * grid : 0;
@@ -496,11 +496,11 @@ static int launch_post_frag(vbmf_ctx* c, int which = 1, const float* In = nullpt
     DISPATCH_MODE(c->mode, {
         if constexpr (MODEc != MODE_F32) {
             if (which == 0) {
-                if (c->NH == 4) { if (short_side) POST_FRAG2(4, 1, false); else POST_FRAG2(4, 4, false); }
-                else { if (short_side) POST_FRAG2(8, 1, false); else POST_FRAG2(8, 2, false); }
+                if (c->NH == 4) { if (short_side) POST_FRAG2(4, 1, false); else POST_FRAG2(4, VBMF_POST2_NXT4, false); }
+                else { if (short_side) POST_FRAG2(8, 1, false); else POST_FRAG2(8, VBMF_POST2_NXT8, false); }
             } else {
-                if (c->NH == 4) { if (short_side) POST_FRAG2(4, 1, true); else POST_FRAG2(4, 4, true); }
-                else { if (short_side) POST_FRAG2(8, 1, true); else POST_FRAG2(8, 2, true); }
+                if (c->NH == 4) { if (short_side) POST_FRAG2(4, 1, true); else POST_FRAG2(4, VBMF_POST2_NXT4, true); }
+                else { if (short_side) POST_FRAG2(8, 1, true); else POST_FRAG2(8, VBMF_POST2_NXT8, true); }
             }
         }
     });
