@@ -189,6 +189,24 @@ def test_hetero_each_update_f32(pkg, L, M, H):
         _cmp_h(f"update {name} {L}x{M} H={H}", qg, qo, 2e-5)
 
 
+@pytest.mark.parametrize("L,M,H", [(900, 500, 128), (700, 420, 160)])
+def test_hetero_run_wide_rank(pkg, L, M, H):
+    """diag_var = true INSIDE the run loop at H >= 128 (16 / 32 accumulator tiles per wave, un-fused post and Gram kernels): the row
+    scaling of B happens after the post kernel, from the fp32 factor, so that kernel must keep storing it and must not leave
+    delta tiles of the un-scaled product (it did neither in the run loops before this test existed)."""
+    Y, po = _mk_hetero(L, M, H, 78)
+    with pkg.capi.Context(L, M, H, y_dtype=pkg.VBMF_Y_BF16) as c:
+        c.set_Y(Y)
+        Ys = np.ascontiguousarray(c.get_Y())
+    po.trYTY = float(np.sum(Ys * Ys))
+    pkg.set_defaults(y_dtype=pkg.VBMF_Y_BF16, factor_dtype=pkg.VBMF_FACTOR_AUTO)
+    pg = _to_pkg_hetero(pkg, po)
+    d_gpu = pkg.vbmf_sparse_(Ys, pg, 4, eps=0.0, diag_var=True)
+    d_ref, n = O.vbmf_sparse_(Ys, po, 4, eps=0.0, full_cov=False, diag_var=True)
+    _cmp_h(f"run4 bf16x2 {L}x{M} H{H}", pg, po, 5e-3)
+    assert pg._last_run[0] == 4 and abs(d_gpu - d_ref) <= 2e-2 * d_ref + 2e-6
+
+
 @pytest.mark.parametrize("mode", ["f32", "bf16x2"])
 def test_hetero_run(pkg, mode):
     L, M, H = 600, 380, 6

@@ -432,7 +432,9 @@ static int launch_post(vbmf_ctx* c, int which, const float* In, int nslab) {
     double* trp = (which == 1 && !c->diagvar && 4 * grid <= c->trpart_cap) ? c->trpart : nullptr;   // (diag_var rescales the rows afterwards)
     c->ntr = trp ? 4 * grid : 0;
     // B side at H >= 128 (bf16 factor modes): delta tiles for the delta-Gram; inside the run loops no fp32 copy of B per sweep
-    uint4* fd = (which == 1 && c->NH >= 4) ? c->FD : nullptr;
+    // (heteroscedastic rows: B = diag(sigmaVecHat) (Y A) SigmaB is scaled AFTER this kernel, from the fp32 factor it stores -- no
+    //  delta tiles of the un-scaled product, and the fp32 store stays)
+    uint4* fd = (which == 1 && c->NH >= 4 && !c->diagvar) ? c->FD : nullptr;
     const int store_fac = (fd != nullptr && c->in_run) ? 0 : 1;
     if (which == 1) c->fd_valid = fd != nullptr;
     if (!store_fac) c->B32_stale = true;
