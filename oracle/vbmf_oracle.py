@@ -401,11 +401,19 @@ def spread_v(v, M, reference_compat=True):
 
 
 def sparse_updateA(Y, p, full_cov=False, reference_compat=True, diag_var=False):
-    """src/vbmf_sparse.jl:176-247 (full_cov with diag_var=false only; the diagonal branch with either noise model)."""
+    """src/vbmf_sparse.jl:176-247, all four (full_cov, diag_var) branches."""
     L, M, H = p.L, p.M, p.H
-    if full_cov and diag_var:
-        raise NotImplementedError("full_cov with diag_var is outside the restated path")
-    if not full_cov and diag_var:                                   # :207-212, 229-230 (heteroscedastic rows)
+    if full_cov and diag_var:                                       # :180-182, :192-193 (sigma enters to the FIRST power here)
+        K = p.BHat.T @ (p.sigmaVecHat[:, None] * p.BHat) + L * np.mean(p.sigmaVecHat) * p.SigmaB
+        p.invSigmaATVec = np.kron(np.eye(M), K) + np.diag(p.CA)
+        p.SigmaATVec = np.linalg.inv(p.invSigmaATVec)
+        p.diagSigmaATVec = np.diag(p.SigmaATVec).copy()
+        BtY = (p.BHat * p.sigmaVecHat[:, None]).T @ Y               # B' diag(sigmaVec) Y
+        p.ATVecHat = p.SigmaATVec @ BtY.T.reshape(M * H)            # :193 (no sigmaHat factor)
+        p.SigmaA = np.zeros((H, H))
+        for m in range(M):
+            p.SigmaA += p.SigmaATVec[m * H:(m + 1) * H, m * H:(m + 1) * H]
+    elif not full_cov and diag_var:                                   # :207-212, 229-230 (heteroscedastic rows)
         sB = p.BHat * p.sigmaVecHat[:, None]
         v = np.sum(sB * sB, axis=0) + L * np.mean(p.sigmaVecHat) * np.diag(p.SigmaB)   # :211 (sigma enters squared)
         prec = spread_v(v, M, reference_compat) + p.CA

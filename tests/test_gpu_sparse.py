@@ -308,6 +308,33 @@ def test_full_cov_logged_trajectory_against_the_reference_record(pkg, golden_dir
     assert abs(p.zeta - 21.72598805535064) < 2e-3 * 21.7
 
 
+@pytest.mark.parametrize("L,M,H", [(300, 150, 6), (420, 60, 40), (400, 30, 100)])
+def test_full_cov_with_heteroscedastic_rows(pkg, L, M, H):
+    """full_cov = true WITH diag_var = true (src/vbmf_sparse.jl:180-182, 192-193): per-column blocks
+    K_m = B' diag(sigmaVec) B + L mean(sigmaVec) SigmaB + diag(CA[m,:]) -- the weighted Gram is an extra reduction over the rows
+    -- and vec(A')_m = inv(K_m) (B' diag(sigmaVec) Y)_m without a sigmaHat factor.  PARITY UNPINNED (no recorded run of this
+    branch): against the oracle's dense kron(...) restatement; then the loop with both switches on."""
+    Y, po = _mk_hetero(L, M, H, 90 + H, H1=2, labels=[3, 20, 25])
+    pkg.set_defaults(y_dtype=pkg.VBMF_Y_F32, factor_dtype=pkg.VBMF_FACTOR_AUTO)
+    Yf = Y.astype(np.float32).astype(np.float64)
+    po.trYTY = float(np.sum(Yf * Yf))
+    O.vbmf_sparse_(Yf, po, 3, eps=0.0, full_cov=False, diag_var=True)       # non-trivial SigmaB / CA / sigmaVecHat
+    pg = _to_pkg_hetero(pkg, po)
+    pkg.sparse_updateA_(Yf, pg, full_cov=True, diag_var=True); O.sparse_updateA(Yf, po, full_cov=True, diag_var=True)
+    _cmp(f"full_cov+diag_var {L}x{M} H{H} updateA", pg, po, 5e-5, ("ATVecHat", "diagSigmaATVec", "SigmaA"))
+    assert np.any(po.SigmaA != np.diag(np.diag(po.SigmaA)))
+    assert np.all(pg.AHat[[3, 20, 25], H - 2:] == 0.0)
+    pg = _to_pkg_hetero(pkg, po)
+    pkg.sparse_updateB_(Yf, pg, diag_var=True); O.sparse_updateB(Yf, po, diag_var=True)     # consumes the full SigmaA
+    _cmp(f"full_cov+diag_var {L}x{M} H{H} updateB", pg, po, 5e-5, ("BHat", "SigmaB"))
+    if M * H <= 4000:
+        pg = _to_pkg_hetero(pkg, po)
+        d_gpu = pkg.vbmf_sparse_(Yf, pg, 5, eps=0.0, full_cov=True, diag_var=True)
+        d_ref, _ = O.vbmf_sparse_(Yf, po, 5, eps=0.0, full_cov=True, diag_var=True)
+        _cmp_h(f"full_cov+diag_var run5 {L}x{M} H{H}", pg, po, 2e-3)
+        assert abs(d_gpu - d_ref) <= 2e-2 * d_ref + 2e-6
+
+
 @pytest.mark.parametrize("L,M,H", [(300, 170, 5), (500, 120, 40), (400, 90, 64), (400, 84, 100)])
 def test_full_cov_against_the_oracle(pkg, L, M, H):
     """Larger shapes (all four register tilings of the per-column inverse: two columns per round up to H = 64, one for
@@ -333,8 +360,8 @@ def test_full_cov_against_the_oracle(pkg, L, M, H):
         lb_gpu, lb_ref = pkg.lowerBound(Yf, _to_pkg(pkg, po)), O.lowerBound(Yf, po)   # the bound of a full-SigmaA state
         report(f"full_cov {L}x{M} H{H} lowerBound of the oracle's state: gpu {lb_gpu:.6f} oracle {lb_ref:.6f}")
         assert abs(lb_gpu - lb_ref) <= 2e-5 * abs(lb_ref)
-    with pytest.raises(NotImplementedError):
-        pkg.sparse_updateA_(Yf, pg, full_cov=True, diag_var=True)
+    with pytest.raises(NotImplementedError):                     # one H x H fp64 block per column must fit a workgroup's registers
+        pkg._check_full_cov(True, False, 129)
 
 
 def test_lower_bound_trimmed(pkg):

@@ -29,19 +29,25 @@ def problem(L, M, H, seed):
 # "straddle": the two shards (2049 / 2048 rows) sit on either side of the narrow-geometry threshold of the H <= 32 kernel;
 # the ranks must still agree on the padded width of the all-reduced Y'B partial (the decision uses the nominal shard size).
 CASES = {"h12": (1531, 700, 12), "h128": (1203, 520, 128), "h200": (901, 420, 200), "sparse": (1101, 480, 6),
-         "hetero": (1101, 480, 6), "trial": (1101, 480, 6), "straddle": (4097, 2100, 12)}
+         "hetero": (1101, 480, 6), "hetero_stop": (1101, 480, 6), "trial": (1101, 480, 6), "straddle": (4097, 2100, 12)}
+# "hetero_stop": the heteroscedastic loop ends EARLY on the device-side stop flag (eps > 0) with sweeps still enqueued behind
+# it, then runs one more updateA! / updateB! on the state the loop left: every collective enqueued after the stop must leave
+# the frozen state -- the all-reduced Grams included -- exactly as the last executed sweep produced it.
+EPS_CASE = {"hetero_stop": float(os.environ.get("VBMF_TEST_EPS", "0.02"))}     # the parent picks eps in a wide gap of the d sequence
+SPARSE_CASES = ("sparse", "hetero", "hetero_stop", "trial")
 TRIAL_H0, TRIAL_M0 = 4, 190
 EPS, SEED = 0.0, 4242
-NITERS = {"h12": 12, "h128": 5, "h200": 5, "sparse": 8, "hetero": 8, "trial": 8, "straddle": 4}
+NITERS = {"h12": 12, "h128": 5, "h200": 5, "sparse": 8, "hetero": 8, "hetero_stop": 14, "trial": 8, "straddle": 4}
 HYPER = dict(alpha0=1e-10, beta0=1e-10, gamma0=1e-10, delta0=1e-10, eta0=1e-10, zeta0=1e-10)
 
 
 def variant_of(pkg, case):
     return {"sparse": pkg.capi.VBMF_VARIANT_SPARSE_DIAG, "hetero": pkg.capi.VBMF_VARIANT_SPARSE_DIAGVAR,
+            "hetero_stop": pkg.capi.VBMF_VARIANT_SPARSE_DIAGVAR,
             "trial": pkg.capi.VBMF_VARIANT_TRIAL_DIAG}.get(case, pkg.capi.VBMF_VARIANT_BASIC)
 
 
-def run_sparse(pkg, ctx, Y, A0, B0, H, niter, hetero, L_global, row0, trial=False):
+def run_sparse(pkg, ctx, Y, A0, B0, H, niter, hetero, L_global, row0, trial=False, eps=EPS, after_stop=False):
     """vbmf_sparse_init's initial state (src/vbmf_sparse.jl:101-153, ca = cb = sigma = 1) on this rank's rows."""
     M = A0.shape[0]
     n = Y.shape[0]
@@ -55,7 +61,10 @@ def run_sparse(pkg, ctx, Y, A0, B0, H, niter, hetero, L_global, row0, trial=Fals
         ctx.trial_set_priors(TRIAL_H0, TRIAL_M0, pri)
         it, d, _ = ctx.trial_run(niter, eps=EPS, est_cb=True, est_priors=True)
     else:
-        it, d, _ = ctx.sparse_run(niter, eps=EPS, est_cb=True)
+        it, d, _ = ctx.sparse_run(niter, eps=eps, est_cb=True)
+    if after_stop:                                   # one more A and B update on the state the (early-stopped) loop left
+        ctx.sparse_step(pkg.capi.SSTEP_A)
+        ctx.sparse_step(pkg.capi.SSTEP_B)
     s = ctx.sparse_get_state()
     out = dict(it=it, d=d, trYY=ctx.trYY(), AHat=s["ATVecHat"].reshape(M, H), BHat=s["BHat"], SigmaA=np.diag(s["SigmaA_diag"]),
                SigmaB=s["SigmaB"], CA_diag=s["CA"], CB_diag=s["CB"], sigma2=s["sigmaHat"], trace=np.zeros(1),
@@ -98,8 +107,9 @@ def main():
             ctx.comm_init(uid[0])
         else:
             ctx.comm_set_transport(pkg.dist.host_staged_transport(lambda a: dist.all_reduce(torch.from_numpy(a))))
-        if case in ("sparse", "hetero", "trial"):
-            res = run_sparse(pkg, ctx, Y[r0:r0 + n], A0, B0[r0:r0 + n], H, NITERS[case], case == "hetero", L, r0, case == "trial")
+        if case in SPARSE_CASES:
+            res = run_sparse(pkg, ctx, Y[r0:r0 + n], A0, B0[r0:r0 + n], H, NITERS[case], case.startswith("hetero"), L, r0, case == "trial",
+                             eps=EPS_CASE.get(case, EPS), after_stop=case in EPS_CASE)
         else:
             res = run(pkg, ctx, Y[r0:r0 + n], A0, B0[r0:r0 + n], H, NITERS[case])
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), row0=r0, nrows=n, **res)

@@ -496,8 +496,7 @@ def _spush(c, p, diag_var=False, full_cov=False):
     hyper = dict(alpha0=p.alpha0, beta0=p.beta0, gamma0=p.gamma0, delta0=p.delta0, eta0=p.eta0, zeta0=p.zeta0)
     c.sparse_set_state(p.ATVecHat, p.diagSigmaATVec, p.CA, p.beta, p.BHat, p.SigmaB, p.CB, p.delta, p.sigmaHat,
                        p.zeta, hyper, labels0=_labels0(p), H1=p.H1)
-    if not diag_var:
-        _push_SigmaA(c, p, full_cov)
+    _push_SigmaA(c, p, full_cov)                                      # either noise model: the caller's SigmaA as it is
     if diag_var:
         c.sparse_set_noise_rows(p.sigmaVecHat, p.zetaVec, float(np.asarray(p.etaVec).reshape(-1)[0]))
 
@@ -515,8 +514,8 @@ def _spull(c, p, diag_var=False):
 
 
 def _check_full_cov(full_cov, diag_var, H):
-    if full_cov and (diag_var or H > 128):
-        raise NotImplementedError("full_cov=true is built for diag_var=false and H <= 128")
+    if full_cov and H > 128:
+        raise NotImplementedError("full_cov=true is built for H <= 128 (either noise model)")
 
 
 def _sone(Y, p, which, diag_var=False, full_cov=False):
@@ -717,8 +716,7 @@ def _dpush(c, p, diag_var=False, full_cov=False):
     hyper = dict(alpha0=p.alpha00, beta0=p.beta00, gamma0=p.gamma0, delta0=p.delta0, eta0=p.eta0, zeta0=p.zeta0)
     c.sparse_set_state(p.ATVecHat, p.diagSigmaATVec, p.CA, p.beta, p.BHat, p.SigmaB, p.CB, p.delta, p.sigmaHat, p.zeta, hyper)
     c.dual_set_priors(p.H0, p.alpha00, p.beta00, p.alpha01, p.beta01, p.alpha0, p.alpha1)
-    if not diag_var:
-        _push_SigmaA(c, p, full_cov)
+    _push_SigmaA(c, p, full_cov)                                      # either noise model: the caller's SigmaA as it is
     if diag_var:
         c.sparse_set_noise_rows(p.sigmaVecHat, p.zetaVec, float(np.asarray(p.etaVec).reshape(-1)[0]))
 
@@ -951,8 +949,7 @@ def _tpush(c, p, diag_var=False, full_cov=False):
     hyper = dict(alpha0=p.alpha01, beta0=p.beta01, gamma0=p.gamma0, delta0=p.delta0, eta0=p.eta0, zeta0=p.zeta0)
     c.sparse_set_state(p.ATVecHat, p.diagSigmaATVec, p.CA, p.beta, p.BHat, p.SigmaB, p.CB, p.delta, p.sigmaHat, p.zeta, hyper)
     c.trial_set_priors(p.H0, p.M0, {k: getattr(p, k) for k in Context.TRIAL_KEYS})
-    if not diag_var:
-        _push_SigmaA(c, p, full_cov)
+    _push_SigmaA(c, p, full_cov)                                      # either noise model: the caller's SigmaA as it is
     if diag_var:
         c.sparse_set_noise_rows(p.sigmaVecHat, p.zetaVec, float(np.asarray(p.etaVec).reshape(-1)[0]))
 

@@ -63,6 +63,14 @@ __global__ __launch_bounds__(256) void sparse_update_a_kernel(const float* __res
     }
 }
 
+// dst[x][h] = sqrt(w[x]) * src[x][h]: B' diag(w) B is then the plain Gram of dst (full_cov with diag_var, :180-182)
+__global__ void sqrt_rowscale_kernel(const float* __restrict__ src, const float* __restrict__ w, float* __restrict__ dst,
+                                     long long n, int Hp, const int* __restrict__ stop) {
+    if (stop && *stop) return;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        dst[i] = sqrtf(w[i / Hp]) * src[i];
+}
+
 // ---- full_cov = true (src/vbmf_sparse.jl:178-202, src/vbmf_dual.jl:218-243, src/vbmf_trial.jl:252-277) ------------------
 // The reference builds invSigmaATVec = sigmaHat * kron(I_M, B'B + L SigmaB) + diag(CA) as a dense MH x MH matrix and
 // inverts it.  That matrix is BLOCK DIAGONAL: M independent H x H blocks  K_m = sigmaHat (B'B + L SigmaB) + diag(CA[m,:]),
@@ -82,7 +90,8 @@ __global__ __launch_bounds__(T * T) void sparse_update_a_full_kernel(const float
                                                                      float* __restrict__ A32, float* __restrict__ dS32,
                                                                      const unsigned char* __restrict__ mask, int hmask_start,
                                                                      long long M, int H, int Hp, double Lg,
-                                                                     double* __restrict__ part, int* __restrict__ ints) {
+                                                                     double* __restrict__ part, int* __restrict__ ints,
+                                                                     const double* __restrict__ Gw = nullptr) {
     extern __shared__ __attribute__((aligned(16))) double lds_full[];
     if (load_stop(ints)) return;
     constexpr int NP = T * R;
@@ -90,14 +99,18 @@ __global__ __launch_bounds__(T * T) void sparse_update_a_full_kernel(const float
     double* strip = lds_full;                      // NB * 4 * NP
     double* pivs = lds_full + NB * 4 * NP;         // NB * NP
     double* pv = lds_full + NB * 5 * NP;           // NB * NP: (B'Y)[:, m] of the two columns
+    // Gw != nullptr: heteroscedastic rows (:180-182, :192-193) -- K_m = B' diag(sigmaVec) B + L mean(sigmaVec) SigmaB + diag(CA[m,:])
+    // with the weighted Gram in Gw ([Hp][Hp]), S_SIGMA2 = mean(sigmaVec), P = B' diag(sigmaVec) Y, and no sigmaHat on the mean
     const double sig = st[lay.scal() + S_SIGMA2];
+    const double gsc = Gw != nullptr ? 1.0 : sig, msc = Gw != nullptr ? 1.0 : sig;
+    const double* G = Gw != nullptr ? Gw : st + lay.GB();
     double k0[R][R], acc[R][R];
 #pragma unroll
     for (int a = 0; a < R; ++a)
 #pragma unroll
         for (int b = 0; b < R; ++b) {
             const int i = ty + T * a, j = tx + T * b;
-            k0[a][b] = (i < H && j < H) ? sig * (st[lay.GB() + (long long)i * lay.Hp + j] + Lg * st[lay.SB() + (long long)i * lay.Hp + j]) : 0.0;
+            k0[a][b] = (i < H && j < H) ? gsc * G[(long long)i * lay.Hp + j] + sig * Lg * st[lay.SB() + (long long)i * lay.Hp + j] : 0.0;
             acc[a][b] = 0.0;
         }
     int bad = 0;
@@ -140,7 +153,7 @@ __global__ __launch_bounds__(T * T) void sparse_update_a_full_kernel(const float
                 for (int b = 0; b < R; ++b) sm += w[q][a][b] * pv[q * NP + tx + T * b];
                 for (int off = T / 2; off > 0; off >>= 1) sm += __shfl_xor(sm, off);   // the T lanes of a row are contiguous
                 if (tx == 0 && i < H) {
-                    float av = (float)(sig * sm);
+                    float av = (float)(msc * sm);
                     if (mask != nullptr && i >= hmask_start && mask[m]) av = 0.f;
                     A32[m * Hp + i] = av;
                 }

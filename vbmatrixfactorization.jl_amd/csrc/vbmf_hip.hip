@@ -64,6 +64,7 @@ struct vbmf_ctx {
     int tiles_per_chunk = 32;
     double* st = nullptr;
     double* gtmp = nullptr;          // [B'B | dB'dB | tr(B'YA), pad] local sums: the send side of the packed all-reduce
+    double* gw = nullptr;            // full_cov with diag_var: [this rank's B' diag(sigmaVec) B | its sum over the ranks], Hp^2 each
     double* trpart = nullptr;        // per-wave shares of tr(B'YA) left by the kernel that produced BHat
     int trpart_cap = 0, ntr = 0;     // ntr: shares waiting for the next B-side Gram reduction (0: none)
     double* ypart = nullptr;         // per-block partials of ||Y||^2 (fixed-order sum)
@@ -72,7 +73,7 @@ struct vbmf_ctx {
     float *dS32 = nullptr, *CA32 = nullptr, *beta32 = nullptr;   // diagSigmaATVec, CA, beta as [Mp][Hp]
     // heteroscedastic rows (variant SPARSE_DIAGVAR): sigmaVecHat / zetaVec, ||Y_l||^2, G = A'A + SigmaA, scaled-B tiles
     bool diagvar = false, Q_valid = false, have_noise = false, noise_mean_reduced = false;
-    double *sigv = nullptr, *zetav = nullptr, *yrow = nullptr, *hpart = nullptr, *vsq = nullptr;
+    double *sigv = nullptr, *zetav = nullptr, *yrow = nullptr, *hpart = nullptr, *vsq = nullptr, *hmean = nullptr;
     float *sig32 = nullptr, *G32 = nullptr;
     uint4 *FBs_alloc = nullptr, *FBs = nullptr;
     double etaVec = 0.0;
@@ -977,7 +978,7 @@ int vbmf_destroy(vbmf_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     prof_harvest(c);
     if (c->comm) ncclCommDestroy(c->comm);
-    void* bufs[] = {c->Y1, c->Y2, c->FA_alloc, c->FB_alloc, c->FD, c->SBf, c->P, c->Q, c->Pred, c->A32, c->B32[0], c->B32[1], c->SA32,
+    void* bufs[] = {c->gw, c->hmean, c->Y1, c->Y2, c->FA_alloc, c->FB_alloc, c->FD, c->SBf, c->P, c->Q, c->Pred, c->A32, c->B32[0], c->B32[1], c->SA32,
                     c->SB32, c->gslab, c->st, c->gtmp, c->ypart, c->trpart, c->ints, c->mask, c->dS32, c->CA32, c->beta32, c->vtab,
                     c->sigv, c->zetav, c->yrow, c->hpart, c->vsq, c->sig32, c->G32, c->FBs_alloc, c->gpart, c->fpart};
     for (void* b : bufs) if (b) hipFree(b);
@@ -1134,6 +1135,7 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
         ALLOC(c->zetav, (size_t)c->Lp * 8);
         ALLOC(c->yrow, (size_t)c->Lp * 8);
         ALLOC(c->hpart, (size_t)cdiv(c->Lp, 256) * 8 + 64);
+        ALLOC(c->hmean, 2 * 8);                    // [this rank's share of mean(sigmaVecHat) | its sum over the ranks]
         ALLOC(c->vsq, (size_t)c->Hp * 8);
         ALLOC(c->sig32, (size_t)c->Lp * 4);
         ALLOC(c->G32, (size_t)c->Hp * c->Hp * 4);
@@ -1864,10 +1866,39 @@ static int sparse_colsum(vbmf_ctx* c) {
 }
 
 template <int R, int T, int NB = 2>
-static void launch_full_a_t(vbmf_ctx* c) {
+static void launch_full_a_t(vbmf_ctx* c, const double* Gw = nullptr) {
     hipLaunchKernelGGL((sparse_update_a_full_kernel<R, T, NB>), dim3(c->fblocks), dim3(T * T), (size_t)(6 * NB * T * R) * sizeof(double), c->stream,
                        c->Pred, (long long)c->d1.XT * 32, c->CA32, c->st, c->lay, c->A32, c->dS32, c->has_mask ? c->mask : nullptr,
-                       (int)(c->H - c->H1), (long long)c->M, (int)c->H, c->Hp, (double)c->Lg, c->fpart, c->ints);
+                       (int)(c->H - c->H1), (long long)c->M, (int)c->H, c->Hp, (double)c->Lg, c->fpart, c->ints, Gw);
+}
+
+// B' diag(sigmaVecHat) B summed over the row shards (full_cov with diag_var, src/vbmf_sparse.jl:180-182): the plain Gram (exact-f32
+// kernel, any H) of sqrt(sigma_l) * B[l,:], formed in the fp32 buffer of the PREVIOUS B (free between the B update's delta-Gram
+// and the next B update).  Local sum in c->gw, reduced OUT OF PLACE into c->gw + Hp^2 (idempotent after the device-side stop,
+// like the two per-sweep reductions); *out: where the result is.
+static int weighted_gram_B(vbmf_ctx* c, const double** out) {
+    const int* stop = c->ints + I_STOP;
+    float* scratch = c->B32[c->bcur ^ 1];
+    const long long nel = (long long)c->Lp * c->Hp;
+    hipLaunchKernelGGL(sqrt_rowscale_kernel, dim3(grid_for(nel, 256, 4096)), dim3(256), 0, c->stream, c->B32[c->bcur], c->sig32, scratch,
+                       nel, c->Hp, stop);
+    const int tpc = c->tiles_per_chunk;
+    const int nchunk = cdiv(c->d2.XT, tpc);
+    const int nw = nchunk * c->NH * c->NH;
+    DISPATCH_NH(c->NH, {
+        hipLaunchKernelGGL((gram_kernel<NHc>), dim3((nw + 3) / 4), dim3(256), 0, c->stream, scratch, (const float*)nullptr, c->gslab, c->d2.XT,
+                           tpc, nchunk, stop);
+    });
+    const int n = c->Hp * c->Hp;
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3((2 * n + 31) / 32), dim3(256), 0, c->stream, c->gslab, nchunk, n, c->gw, (double*)nullptr,
+                       stop, (const double*)nullptr, 0, (double*)nullptr);
+    HIPCHK(c, hipGetLastError());
+    *out = c->gw;
+    if (sharded(c)) {
+        TRY(allreduce_sum(c, c->gw, c->gw + n, (size_t)n, true));
+        *out = c->gw + n;
+    }
+    return VBMF_OK;
 }
 
 static int do_sparse_update_A(vbmf_ctx* c, bool reuse_P = false) {
@@ -1897,10 +1928,12 @@ static int do_sparse_update_A(vbmf_ctx* c, bool reuse_P = false) {
     if (c->full_cov) {
         // :178-202 -- M independent H x H inverses (the dense MH x MH matrix of the reference is block diagonal)
         const int H = (int)c->H;
-        if (H <= 16) launch_full_a_t<1, 16>(c);
-        else if (H <= 32) launch_full_a_t<2, 16>(c);
-        else if (H <= 64) launch_full_a_t<4, 16>(c);
-        else launch_full_a_t<8, 16, 1>(c);                 // 64 < H <= 128: one column per round and workgroup
+        const double* Gw = nullptr;
+        if (c->diagvar) TRY(weighted_gram_B(c, &Gw));
+        if (H <= 16) launch_full_a_t<1, 16>(c, Gw);
+        else if (H <= 32) launch_full_a_t<2, 16>(c, Gw);
+        else if (H <= 64) launch_full_a_t<4, 16>(c, Gw);
+        else launch_full_a_t<8, 16, 1>(c, Gw);             // 64 < H <= 128: one column per round and workgroup
         hipLaunchKernelGGL(full_sa_fold_kernel, dim3(cdiv(c->Hp * c->Hp, 256)), dim3(256), 0, c->stream, c->fpart, c->fblocks, c->Hp, c->st, c->lay, stop);
         HIPCHK(c, hipGetLastError());
         TRY(launch_retile(c, 0, true));
@@ -1976,10 +2009,12 @@ static int do_hetero_sigma(vbmf_ctx* c) {
     hipLaunchKernelGGL(hetero_sigma_kernel, dim3(nb), dim3(256), 0, c->stream, c->Q, (long long)c->d2.XT * 32, c->B32[c->bcur], c->G32,
                        c->yrow, c->st, c->lay, c->etaVec, (long long)c->L, (int)c->H, c->Hp, c->zetav, c->sigv, c->sig32, c->hpart, stop);
     if (sharded(c)) {
-        // this rank's share of the mean goes through the staging buffer: after `stop` the state must not be re-summed
-        hipLaunchKernelGGL(hetero_mean_kernel, dim3(1), dim3(256), 0, c->stream, c->hpart, nb, (double)c->Lg, c->gtmp, stop);
-        TRY(allreduce_sum(c, c->gtmp, 1, true));
-        hipLaunchKernelGGL(gated_copy_kernel, dim3(1), dim3(64), 0, c->stream, c->gtmp, c->st + c->lay.scal() + S_SIGMA2, 1, stop);
+        // this rank's share of the mean goes through a staging pair of its own, reduced OUT OF PLACE (after `stop` the gated
+        // kernels leave the share alone and the re-reduction reproduces the same sum; c->gtmp is NOT scratch: it holds the B
+        // side's partials, which a sweep enqueued after the stop reduces again), then a gated copy into the state
+        hipLaunchKernelGGL(hetero_mean_kernel, dim3(1), dim3(256), 0, c->stream, c->hpart, nb, (double)c->Lg, c->hmean, stop);
+        TRY(allreduce_sum(c, c->hmean, c->hmean + 1, 1, true));
+        hipLaunchKernelGGL(gated_copy_kernel, dim3(1), dim3(64), 0, c->stream, c->hmean + 1, c->st + c->lay.scal() + S_SIGMA2, 1, stop);
     } else {
         hipLaunchKernelGGL(hetero_mean_kernel, dim3(1), dim3(256), 0, c->stream, c->hpart, nb, (double)c->L, c->st + c->lay.scal() + S_SIGMA2, stop);
     }
@@ -2263,7 +2298,6 @@ int vbmf_sparse_run(vbmf_ctx* c, int64_t niter, double eps, int est_cb, int64_t*
 int vbmf_sparse_set_full_cov(vbmf_ctx* c, int on) {
     if (!c) return VBMF_ERR_INVALID;
     if (!c->sparse) FAIL(c, VBMF_ERR_INVALID, "not a sparse context");
-    if (on && c->diagvar) FAIL(c, VBMF_ERR_UNSUPPORTED, "full_cov with diag_var is not built");
     if (on && c->H > 128) FAIL(c, VBMF_ERR_UNSUPPORTED, "full_cov is built for H <= 128 (one H x H fp64 block per column of Y must fit a workgroup's registers)");
     HIPCHK(c, hipSetDevice(c->o.device));
     if (on && !c->fpart) {
@@ -2272,6 +2306,11 @@ int vbmf_sparse_set_full_cov(vbmf_ctx* c, int on) {
         const size_t bytes = (size_t)c->fblocks * c->Hp * c->Hp * 8;
         HIPCHK(c, hipMalloc((void**)&c->fpart, bytes));
         HIPCHK(c, hipMemset(c->fpart, 0, bytes));
+    }
+    if (on && c->diagvar && !c->gw) {
+        const size_t bytes = (size_t)2 * c->Hp * c->Hp * 8;
+        HIPCHK(c, hipMalloc((void**)&c->gw, bytes));
+        HIPCHK(c, hipMemset(c->gw, 0, bytes));
     }
     c->full_cov = on != 0;
     return VBMF_OK;

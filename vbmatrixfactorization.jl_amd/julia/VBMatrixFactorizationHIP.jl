@@ -391,15 +391,15 @@ end
 "vbmf_sparse! -- src/vbmf_sparse.jl:344-410 (returns d, like the reference)"
 function vbmf_sparse!(Y::Array{Float64,2}, params::vbmf_sparse_parameters, niter::Int; eps::Float64 = 1e-6, diag_var::Bool = false,
                       full_cov::Bool = false, logdir = "", desc = "", verb = false, est_cb::Bool = true)
-    full_cov && (diag_var || params.H > 128) && error("full_cov=true is built for diag_var=false and H <= 128")
+    full_cov && params.H > 128 && error("full_cov=true is built for H <= 128 (either noise model)")
     logdir == "" || error("trajectory logging lives in the Python host (data_manip.py)")
     c = sparse_ctx_for(Y, params.H, diag_var); spush!(c, params, diag_var)
-    diag_var || set_full_cov!(c, params, full_cov)
+    set_full_cov!(c, params, full_cov)
     iters = Ref{Int64}(0); d = Ref{Float64}(0.0)
     chk(c.h, ccall((:vbmf_sparse_run, libvbmf), Cint, (Ptr{Cvoid}, Int64, Float64, Cint, Ref{Int64}, Ref{Float64}, Ptr{Float64}),
                    c.h, niter, eps, est_cb, iters, d, C_NULL))
     spull!(c, params, diag_var)
-    diag_var || pull_SigmaA!(c, params)
+    pull_SigmaA!(c, params)
     params.L * params.M <= (1 << 24) && (params.YHat = params.BHat * params.AHat')            # :396
     verb && print("Factorization finished after ", iters[], " iterations, eps = ", d[], "\n")
     return d[]
@@ -474,7 +474,7 @@ end
 "vbmf_dual! -- src/vbmf_dual.jl:455-530 (returns d); est_priors: the hyper-prior fits of :393-434 run on the device"
 function vbmf_dual!(Y::Array{Float64,2}, p::vbmf_dual_parameters, niter::Int; eps::Float64 = 1e-6, diag_var::Bool = false,
                     full_cov::Bool = false, logdir = "", desc = "", verb = false, est_priors = true, est_cb::Bool = true)
-    full_cov && (diag_var || p.H > 128) && error("full_cov=true is built for diag_var=false and H <= 128")
+    full_cov && p.H > 128 && error("full_cov=true is built for H <= 128 (either noise model)")
     logdir == "" || error("trajectory logging lives in the Python host (data_manip.py)")
     c = sparse_ctx_for(Y, p.H, diag_var; variant = diag_var ? 5 : 3)          # VBMF_VARIANT_DUAL_DIAGVAR / _DUAL_DIAG
     hy = Ref(SparseHyper(p.alpha00, p.beta00, p.gamma0, p.delta0, p.eta0, p.zeta0))
@@ -485,8 +485,9 @@ function vbmf_dual!(Y::Array{Float64,2}, p::vbmf_dual_parameters, niter::Int; ep
         C_NULL, 0, 0))
     chk(c.h, ccall((:vbmf_dual_set_priors, libvbmf), Cint, (Ptr{Cvoid}, Int64, Float64, Float64, Float64, Float64, Float64, Float64),
                    c.h, p.H0, p.alpha00, p.beta00, p.alpha01, p.beta01, p.alpha0, p.alpha1))
-    diag_var ? chk(c.h, ccall((:vbmf_sparse_set_noise_rows, libvbmf), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Float64),
-                              c.h, p.sigmaVecHat, p.zetaVec, p.etaVec[1])) : set_full_cov!(c, p, full_cov)
+    diag_var && chk(c.h, ccall((:vbmf_sparse_set_noise_rows, libvbmf), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Float64),
+                               c.h, p.sigmaVecHat, p.zetaVec, p.etaVec[1]))
+    set_full_cov!(c, p, full_cov)
     iters = Ref{Int64}(0); d = Ref{Float64}(0.0)
     chk(c.h, ccall((:vbmf_dual_run, libvbmf), Cint, (Ptr{Cvoid}, Int64, Float64, Cint, Cint, Ref{Int64}, Ref{Float64}, Ptr{Float64}),
                    c.h, niter, eps, est_cb, est_priors, iters, d, C_NULL))
@@ -574,7 +575,7 @@ end
 "vbmf_trial! -- src/vbmf_trial.jl:528-604 (returns d); est_priors: the six hyper-prior fits of :442-507 run on the device"
 function vbmf_trial!(Y::Array{Float64,2}, p::vbmf_trial_parameters, niter::Int; eps::Float64 = 1e-6, diag_var::Bool = false,
                      full_cov::Bool = false, logdir = "", desc = "", verb = false, est_priors = true, est_cb::Bool = true)
-    full_cov && (diag_var || p.H > 128) && error("full_cov=true is built for diag_var=false and H <= 128")
+    full_cov && p.H > 128 && error("full_cov=true is built for H <= 128 (either noise model)")
     logdir == "" || error("trajectory logging lives in the Python host (data_manip.py)")
     c = sparse_ctx_for(Y, p.H, diag_var; variant = diag_var ? 6 : 4)          # VBMF_VARIANT_TRIAL_DIAGVAR / _TRIAL_DIAG
     hy = Ref(SparseHyper(p.alpha01, p.beta01, p.gamma0, p.delta0, p.eta0, p.zeta0))
@@ -585,8 +586,9 @@ function vbmf_trial!(Y::Array{Float64,2}, p::vbmf_trial_parameters, niter::Int; 
         C_NULL, 0, 0))
     pri = Float64[p.alpha01, p.beta01, p.alpha02, p.beta02, p.alpha03, p.beta03, p.alpha1, p.alpha2, p.alpha3]
     chk(c.h, ccall((:vbmf_trial_set_priors, libvbmf), Cint, (Ptr{Cvoid}, Int64, Int64, Ptr{Float64}), c.h, p.H0, p.M0, pri))
-    diag_var ? chk(c.h, ccall((:vbmf_sparse_set_noise_rows, libvbmf), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Float64),
-                              c.h, p.sigmaVecHat, p.zetaVec, p.etaVec[1])) : set_full_cov!(c, p, full_cov)
+    diag_var && chk(c.h, ccall((:vbmf_sparse_set_noise_rows, libvbmf), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Float64),
+                               c.h, p.sigmaVecHat, p.zetaVec, p.etaVec[1]))
+    set_full_cov!(c, p, full_cov)
     iters = Ref{Int64}(0); d = Ref{Float64}(0.0)
     chk(c.h, ccall((:vbmf_trial_run, libvbmf), Cint, (Ptr{Cvoid}, Int64, Float64, Cint, Cint, Ref{Int64}, Ref{Float64}, Ptr{Float64}),
                    c.h, niter, eps, est_cb, est_priors, iters, d, C_NULL))
