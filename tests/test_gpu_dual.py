@@ -246,6 +246,25 @@ def test_dual_full_cov_as_the_mil_callers_run_it(pkg):
     assert np.any(pg.SigmaA != np.diag(np.diag(pg.SigmaA))) and abs(d_gpu - d_ref) <= 2e-2 * d_ref + 2e-6
 
 
+def test_dual_full_cov_with_heteroscedastic_rows(pkg):
+    """vbmf_dual! with full_cov = true AND diag_var = true (src/vbmf_dual.jl:218-243 with the row-noise forms of :220-222,
+    :232-233 -- the sparse model's bodies): 6 sweeps with the prior fits against the oracle's dense restatement.  Unpinned."""
+    L, M, H, H0 = 320, 150, 6, 4
+    rng = np.random.default_rng(277)
+    Y, A, B = O.toy_matrix(L, M, H, 0.0, rng)
+    Y = (B * np.linspace(1.0, 2.5, H)) @ A.T + rng.uniform(0.02, 0.4, (L, 1)) * rng.standard_normal((L, M))
+    po = O.vbmf_dual_init(Y, H, H0, ca=1.0, cb=1.0, sigma=1.0, rng=np.random.default_rng(278), materialize_yhat=False)
+    pkg.set_defaults(y_dtype=pkg.VBMF_Y_F32, factor_dtype=pkg.VBMF_FACTOR_AUTO)
+    Yf = Y.astype(np.float32).astype(np.float64)
+    po.trYTY = float(np.sum(Yf * Yf))
+    pg = _to_pkg(pkg, po)
+    pg.sigmaVecHat, pg.etaVec, pg.zetaVec = po.sigmaVecHat.copy(), po.etaVec.copy(), po.zetaVec.copy()
+    d_gpu = pkg.vbmf_dual_(Yf, pg, 6, eps=0.0, full_cov=True, diag_var=True, est_priors=True)
+    d_ref, n = O.vbmf_dual_(Yf, po, 6, eps=0.0, full_cov=True, diag_var=True, est_priors=True)
+    _cmp("full_cov+diag_var run6 f32", pg, po, 2e-3, FIELDS + ("sigmaVecHat", "zetaVec"), priors_tol=2e-3)
+    assert np.any(pg.SigmaA != np.diag(np.diag(pg.SigmaA))) and abs(d_gpu - d_ref) <= 2e-2 * d_ref + 2e-6
+
+
 def test_dual_lower_bound_trimmed(pkg):
     """lowerBoundTrimmed of the two-group model (src/vbmf_dual.jl:606-617): only the vec fields are trimmed there, the
     per-group fields stay whole -- so MH, the CA-weighted second moment and H(vec(A')) change, the group terms do not."""

@@ -237,3 +237,39 @@ def test_grouped_prior_fit_keeps_the_value_without_a_sign_change():
     x = O._dual_fit_shape(12, np.log(2.0), 1.5, np.full(12, 3.0), 0.123)
     from scipy.special import digamma
     assert digamma(x) == pytest.approx(np.log(2.0) + digamma(1.5) - np.log(3.0), rel=1e-12)
+
+
+def test_full_covariance_with_row_noise_is_blockwise_and_reduces_to_the_homoscedastic_branch():
+    """updateA!, full_cov = true with diag_var = true (src/vbmf_sparse.jl:180-182, 192-193) -- no recorded run pins this branch:
+    (i) written with diagm(sigmaVecHat) and kron(eye(M), .) as in the source, it equals M independent H x H solves with
+    K = B' diag(sigma) B + L mean(sigma) SigmaB; (ii) with every row precision equal to s it IS the homoscedastic full branch at
+    sigmaHat = s (that one is pinned by the reference's recorded sparse run)."""
+    rng = np.random.default_rng(16)
+    L, M, H = 14, 7, 3
+    Y = rng.standard_normal((L, M))
+    p = O.vbmf_sparse_init(Y, H, rng=rng)
+    p.SigmaB = np.diag(rng.uniform(0.1, 1.0, H)); p.CA = rng.uniform(0.5, 2.0, M * H)
+    p.sigmaVecHat = rng.uniform(0.3, 3.0, L)
+    q = copy.deepcopy(p)
+    O.sparse_updateA(Y, p, full_cov=True, diag_var=True)
+    # (i) the source's dense form, literally
+    inv_full = np.kron(np.eye(M), q.BHat.T @ np.diag(q.sigmaVecHat) @ q.BHat + L * np.mean(q.sigmaVecHat) * q.SigmaB) + np.diag(q.CA)
+    S = np.linalg.inv(inv_full)
+    vecA = S @ (q.BHat.T @ np.diag(q.sigmaVecHat) @ Y).T.reshape(M * H)
+    assert np.allclose(p.ATVecHat, vecA, rtol=1e-12, atol=1e-14)
+    K = q.BHat.T @ (q.sigmaVecHat[:, None] * q.BHat) + L * np.mean(q.sigmaVecHat) * q.SigmaB
+    SA = np.zeros((H, H))
+    for m in range(M):
+        Sm = np.linalg.inv(K + np.diag(q.CA[m * H:(m + 1) * H]))
+        SA += Sm
+        assert np.allclose(p.diagSigmaATVec[m * H:(m + 1) * H], np.diag(Sm), rtol=1e-11)
+        assert np.allclose(p.AHat[m], Sm @ (q.BHat.T @ (q.sigmaVecHat * Y[:, m])), rtol=1e-10, atol=1e-13)
+    assert np.allclose(p.SigmaA, SA, rtol=1e-11)
+    # (ii) constant row precision = the homoscedastic branch
+    s = 1.7
+    a, b = copy.deepcopy(q), copy.deepcopy(q)
+    a.sigmaVecHat = np.full(L, s); b.sigmaHat = s
+    O.sparse_updateA(Y, a, full_cov=True, diag_var=True)
+    O.sparse_updateA(Y, b, full_cov=True, diag_var=False)
+    for f in ("ATVecHat", "diagSigmaATVec", "SigmaA"):
+        assert np.allclose(getattr(a, f), getattr(b, f), rtol=1e-11, atol=1e-14), f
