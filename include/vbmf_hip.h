@@ -185,8 +185,9 @@ int vbmf_sparse_lower_bound_trimmed(vbmf_ctx* ctx, int clamp, double trim, doubl
 /* full_cov = true of updateA! (src/vbmf_sparse.jl:178-202; dual :218-243; trial :252-277).  The reference's dense MH x MH
  * invSigmaATVec = sigmaHat*kron(I_M, B'B + L*SigmaB) + diag(CA) is block diagonal, so the device inverts the M H x H blocks
  * (one workgroup per column of Y) and never forms it: diagSigmaATVec = the blocks' diagonals, SigmaA = their sum (a full
- * H x H matrix).  Applies to VBMF_SSTEP_A, the run loops and run_fixed_basis from then on.  H <= 128 (the H x H fp64 block of
- * a column lives in one workgroup's registers; two columns per round up to H = 64, one above).  Either noise model: in the
+ * H x H matrix).  Applies to VBMF_SSTEP_A, the run loops and run_fixed_basis from then on.  Up to H = 128 the H x H fp64 block of
+ * a column lives in one workgroup's registers (two columns per round up to H = 64, one above); 128 < H <= 256 goes through a
+ * blocked Schur inverse in a per-workgroup global workspace (~0.4 ms per column: for small M).  Either noise model: in the
  * *_DIAGVAR variants (:180-182, :192-193) the blocks are B' diag(sigmaVec) B + L mean(sigmaVec) SigmaB + diag(CA[m,:]) and the
  * mean carries no sigmaHat factor.  The dense SigmaATVec / invSigmaATVec fields are not materialised. */
 int vbmf_sparse_set_full_cov(vbmf_ctx* ctx, int on);

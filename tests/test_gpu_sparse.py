@@ -335,10 +335,11 @@ def test_full_cov_with_heteroscedastic_rows(pkg, L, M, H):
         assert abs(d_gpu - d_ref) <= 2e-2 * d_ref + 2e-6
 
 
-@pytest.mark.parametrize("L,M,H", [(300, 170, 5), (500, 120, 40), (400, 90, 64), (400, 84, 100)])
+@pytest.mark.parametrize("L,M,H", [(300, 170, 5), (500, 120, 40), (400, 90, 64), (400, 84, 100), (500, 84, 160)])
 def test_full_cov_against_the_oracle(pkg, L, M, H):
     """Larger shapes (all four register tilings of the per-column inverse: two columns per round up to H = 64, one for
-    64 < H <= 128), label mask included, against the oracle's dense kron(...) restatement; then 6 sweeps of the loop."""
+    64 < H <= 128; the blocked Schur inverse through a global workspace for H = 160), label mask included, against the oracle's
+    dense kron(...) restatement; then 6 sweeps of the loop."""
     Y, po = _mk(L, M, H, 60 + H, H1=2, labels=[3, 50, 80])
     pkg.set_defaults(y_dtype=pkg.VBMF_Y_F32, factor_dtype=pkg.VBMF_FACTOR_AUTO)
     Yf = Y.astype(np.float32).astype(np.float64)
@@ -360,8 +361,8 @@ def test_full_cov_against_the_oracle(pkg, L, M, H):
         lb_gpu, lb_ref = pkg.lowerBound(Yf, _to_pkg(pkg, po)), O.lowerBound(Yf, po)   # the bound of a full-SigmaA state
         report(f"full_cov {L}x{M} H{H} lowerBound of the oracle's state: gpu {lb_gpu:.6f} oracle {lb_ref:.6f}")
         assert abs(lb_gpu - lb_ref) <= 2e-5 * abs(lb_ref)
-    with pytest.raises(NotImplementedError):                     # one H x H fp64 block per column must fit a workgroup's registers
-        pkg._check_full_cov(True, False, 129)
+    with pytest.raises(NotImplementedError):                     # H > 256: beyond every kernel of the library
+        pkg._check_full_cov(True, False, 257)
 
 
 def test_lower_bound_trimmed(pkg):

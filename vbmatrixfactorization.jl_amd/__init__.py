@@ -514,8 +514,8 @@ def _spull(c, p, diag_var=False):
 
 
 def _check_full_cov(full_cov, diag_var, H):
-    if full_cov and H > 128:
-        raise NotImplementedError("full_cov=true is built for H <= 128 (either noise model)")
+    if full_cov and H > 256:
+        raise NotImplementedError("full_cov=true is built for H <= 256 (either noise model)")
 
 
 def _sone(Y, p, which, diag_var=False, full_cov=False):

@@ -178,6 +178,73 @@ __global__ __launch_bounds__(T * T) void sparse_update_a_full_kernel(const float
             if (i < Hp && j < Hp) part[(long long)blockIdx.x * Hp * Hp + (long long)i * Hp + j] = acc[a][b];
         }
 }
+// 128 < H <= 256 (Hp = 256): a 256 x 256 fp64 block is the whole register file of a CU, so the column's block goes through the
+// blocked Schur inverse of the control chain (inv256_schur, ctrl_kernels.hpp: two 128 x 128 register-tiled inverses + four
+// LDS-panelled fp64 GEMMs) with the matrices in a per-workgroup GLOBAL workspace ws[b] = [K | inv(K) | W | S] (1.25 MiB, L2).
+// One 1024-thread workgroup per column and round; the running sum of the blocks lives in part[b] (read-modify-write: the
+// 64 values per thread would not fit beside the inverse's tiles).  ~0.4 ms per column: a correctness path for small M (the MIL
+// callers gate full_cov by M H <= 3200; the reference's own route inverts the dense MH x MH matrix).
+constexpr long long FULL256_WS = 2 * 256 * 256 + 2 * 128 * 128;           // doubles per workgroup
+__global__ __launch_bounds__(1024) void sparse_update_a_full256_kernel(const float* __restrict__ P, long long ldP,
+                                                                       const float* __restrict__ CA32,
+                                                                       const double* __restrict__ st, StateLayout lay,
+                                                                       float* __restrict__ A32, float* __restrict__ dS32,
+                                                                       const unsigned char* __restrict__ mask, int hmask_start,
+                                                                       long long M, int H, double Lg, double* __restrict__ part,
+                                                                       int* __restrict__ ints, const double* __restrict__ Gw,
+                                                                       double* __restrict__ ws) {
+    extern __shared__ __attribute__((aligned(16))) double lds_f256[];
+    if (load_stop(ints)) return;
+    constexpr int Hp = 256;
+    double* Kg = ws + (long long)blockIdx.x * FULL256_WS;
+    double* Ki = Kg + Hp * Hp;
+    double* Wm = Ki + Hp * Hp;
+    double* Sm = Wm + 128 * 128;
+    double* pivs = lds_f256 + 2 * 16 * GEMM_LD + 512;
+    double* pv = pivs + 256;
+    double* mypart = part + (long long)blockIdx.x * Hp * Hp;
+    const double sig = st[lay.scal() + S_SIGMA2];
+    const double gsc = Gw != nullptr ? 1.0 : sig, msc = Gw != nullptr ? 1.0 : sig;   // (see sparse_update_a_full_kernel)
+    const double* G = Gw != nullptr ? Gw : st + lay.GB();
+    for (int t = threadIdx.x; t < Hp * Hp; t += 1024) mypart[t] = 0.0;
+    int bad = 0;
+    for (long long m = blockIdx.x; m < M; m += gridDim.x) {
+        for (int t = threadIdx.x; t < Hp * Hp; t += 1024) {
+            const int i = t >> 8, j = t & 255;
+            double v = (i == j) ? 1.0 : 0.0;                             // identity padding
+            if (i < H && j < H) {
+                v = gsc * G[(long long)i * lay.Hp + j] + sig * Lg * st[lay.SB() + (long long)i * lay.Hp + j];
+                if (i == j) v += (double)CA32[m * Hp + i];
+            }
+            Kg[t] = v;
+        }
+        if (threadIdx.x < Hp) pv[threadIdx.x] = threadIdx.x < H ? (double)P[(long long)threadIdx.x * ldP + m] : 0.0;
+        __syncthreads();
+        inv256_schur(Kg, Ki, Hp, Wm, Sm, lds_f256, pivs);
+        __syncthreads();
+        if (threadIdx.x < H) { const double pq = pivs[threadIdx.x]; if (!(pq > 0.0) || !isfinite(pq)) bad = 1; }
+        {   // vec(A')[m,:] = msc * inv(K_m) (B'Y)[:, m]: four threads per row, 64 columns each
+            const int i = threadIdx.x >> 2, q = threadIdx.x & 3;
+            double sm = 0.0;
+            for (int j = q * 64; j < q * 64 + 64; ++j) sm += Ki[i * Hp + j] * pv[j];
+            sm += __shfl_xor(sm, 1);
+            sm += __shfl_xor(sm, 2);
+            if (q == 0 && i < H) {
+                float av = (float)(msc * sm);
+                if (mask != nullptr && i >= hmask_start && mask[m]) av = 0.f;
+                A32[m * Hp + i] = av;
+                dS32[m * Hp + i] = (float)Ki[i * Hp + i];
+            }
+        }
+        for (int t = threadIdx.x; t < Hp * Hp; t += 1024) {
+            const int i = t >> 8, j = t & 255;
+            if (i < H && j < H) mypart[t] += Ki[t];
+        }
+        __syncthreads();                                                // the workspace and pv are rewritten by the next round
+    }
+    if (bad) atomicExch(ints + I_ERR, 1);
+}
+
 // SigmaA = sum over the blocks' partial sums, fixed order
 __global__ __launch_bounds__(256) void full_sa_fold_kernel(const double* __restrict__ part, int nblocks, int Hp,
                                                            double* __restrict__ st, StateLayout lay, const int* __restrict__ stop) {

@@ -88,6 +88,7 @@ struct vbmf_ctx {
     bool full_cov = false;
     bool narrow = false;             // NarrowCfg geometry of the streaming kernel (small problems)
     double* fpart = nullptr;         // per-block sums of Sigma_m
+    double* fws = nullptr;           // full_cov, H > 128: per-workgroup [K | inv(K) | W | S] of the blocked Schur inverse
     int fblocks = 0;
     vbmf_sparse_hyper hyp{};
     double alpha = 0, gamma_ = 0, eta = 0;
@@ -978,7 +979,7 @@ int vbmf_destroy(vbmf_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     prof_harvest(c);
     if (c->comm) ncclCommDestroy(c->comm);
-    void* bufs[] = {c->gw, c->hmean, c->Y1, c->Y2, c->FA_alloc, c->FB_alloc, c->FD, c->SBf, c->P, c->Q, c->Pred, c->A32, c->B32[0], c->B32[1], c->SA32,
+    void* bufs[] = {c->gw, c->hmean, c->fws, c->Y1, c->Y2, c->FA_alloc, c->FB_alloc, c->FD, c->SBf, c->P, c->Q, c->Pred, c->A32, c->B32[0], c->B32[1], c->SA32,
                     c->SB32, c->gslab, c->st, c->gtmp, c->ypart, c->trpart, c->ints, c->mask, c->dS32, c->CA32, c->beta32, c->vtab,
                     c->sigv, c->zetav, c->yrow, c->hpart, c->vsq, c->sig32, c->G32, c->FBs_alloc, c->gpart, c->fpart};
     for (void* b : bufs) if (b) hipFree(b);
@@ -1933,7 +1934,11 @@ static int do_sparse_update_A(vbmf_ctx* c, bool reuse_P = false) {
         if (H <= 16) launch_full_a_t<1, 16>(c, Gw);
         else if (H <= 32) launch_full_a_t<2, 16>(c, Gw);
         else if (H <= 64) launch_full_a_t<4, 16>(c, Gw);
-        else launch_full_a_t<8, 16, 1>(c, Gw);             // 64 < H <= 128: one column per round and workgroup
+        else if (H <= 128) launch_full_a_t<8, 16, 1>(c, Gw);   // 64 < H <= 128: one column per round and workgroup
+        else                                               // 128 < H <= 256: blocked Schur inverse through a global workspace
+            hipLaunchKernelGGL(sparse_update_a_full256_kernel, dim3(c->fblocks), dim3(1024), (size_t)(2 * 16 * GEMM_LD + 512 + 256 + 256) * sizeof(double),
+                               c->stream, c->Pred, (long long)c->d1.XT * 32, c->CA32, c->st, c->lay, c->A32, c->dS32,
+                               c->has_mask ? c->mask : nullptr, (int)(c->H - c->H1), (long long)c->M, H, (double)c->Lg, c->fpart, c->ints, Gw, c->fws);
         hipLaunchKernelGGL(full_sa_fold_kernel, dim3(cdiv(c->Hp * c->Hp, 256)), dim3(256), 0, c->stream, c->fpart, c->fblocks, c->Hp, c->st, c->lay, stop);
         HIPCHK(c, hipGetLastError());
         TRY(launch_retile(c, 0, true));
@@ -2298,11 +2303,12 @@ int vbmf_sparse_run(vbmf_ctx* c, int64_t niter, double eps, int est_cb, int64_t*
 int vbmf_sparse_set_full_cov(vbmf_ctx* c, int on) {
     if (!c) return VBMF_ERR_INVALID;
     if (!c->sparse) FAIL(c, VBMF_ERR_INVALID, "not a sparse context");
-    if (on && c->H > 128) FAIL(c, VBMF_ERR_UNSUPPORTED, "full_cov is built for H <= 128 (one H x H fp64 block per column of Y must fit a workgroup's registers)");
+    if (on && c->H > 256) FAIL(c, VBMF_ERR_UNSUPPORTED, "full_cov is built for H <= 256");
     HIPCHK(c, hipSetDevice(c->o.device));
     if (on && !c->fpart) {
-        // two columns per round and workgroup (one for H > 64)
-        c->fblocks = (int)std::max<int64_t>(1, std::min<int64_t>(c->H > 64 ? c->M : (c->M + 1) / 2, 1024));
+        // two columns per round and workgroup (one for H > 64); H > 128: one 1024-thread workgroup per CU with its own workspace
+        c->fblocks = (int)std::max<int64_t>(1, std::min<int64_t>(c->H > 64 ? c->M : (c->M + 1) / 2, c->H > 128 ? NUM_CU : 1024));
+        if (c->H > 128) HIPCHK(c, hipMalloc((void**)&c->fws, (size_t)c->fblocks * FULL256_WS * 8));
         const size_t bytes = (size_t)c->fblocks * c->Hp * c->Hp * 8;
         HIPCHK(c, hipMalloc((void**)&c->fpart, bytes));
         HIPCHK(c, hipMemset(c->fpart, 0, bytes));

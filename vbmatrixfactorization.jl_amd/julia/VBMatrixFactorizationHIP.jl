@@ -391,7 +391,7 @@ end
 "vbmf_sparse! -- src/vbmf_sparse.jl:344-410 (returns d, like the reference)"
 function vbmf_sparse!(Y::Array{Float64,2}, params::vbmf_sparse_parameters, niter::Int; eps::Float64 = 1e-6, diag_var::Bool = false,
                       full_cov::Bool = false, logdir = "", desc = "", verb = false, est_cb::Bool = true)
-    full_cov && params.H > 128 && error("full_cov=true is built for H <= 128 (either noise model)")
+    full_cov && params.H > 256 && error("full_cov=true is built for H <= 256 (either noise model)")
     logdir == "" || error("trajectory logging lives in the Python host (data_manip.py)")
     c = sparse_ctx_for(Y, params.H, diag_var); spush!(c, params, diag_var)
     set_full_cov!(c, params, full_cov)
@@ -474,7 +474,7 @@ end
 "vbmf_dual! -- src/vbmf_dual.jl:455-530 (returns d); est_priors: the hyper-prior fits of :393-434 run on the device"
 function vbmf_dual!(Y::Array{Float64,2}, p::vbmf_dual_parameters, niter::Int; eps::Float64 = 1e-6, diag_var::Bool = false,
                     full_cov::Bool = false, logdir = "", desc = "", verb = false, est_priors = true, est_cb::Bool = true)
-    full_cov && p.H > 128 && error("full_cov=true is built for H <= 128 (either noise model)")
+    full_cov && p.H > 256 && error("full_cov=true is built for H <= 256 (either noise model)")
     logdir == "" || error("trajectory logging lives in the Python host (data_manip.py)")
     c = sparse_ctx_for(Y, p.H, diag_var; variant = diag_var ? 5 : 3)          # VBMF_VARIANT_DUAL_DIAGVAR / _DUAL_DIAG
     hy = Ref(SparseHyper(p.alpha00, p.beta00, p.gamma0, p.delta0, p.eta0, p.zeta0))
@@ -575,7 +575,7 @@ end
 "vbmf_trial! -- src/vbmf_trial.jl:528-604 (returns d); est_priors: the six hyper-prior fits of :442-507 run on the device"
 function vbmf_trial!(Y::Array{Float64,2}, p::vbmf_trial_parameters, niter::Int; eps::Float64 = 1e-6, diag_var::Bool = false,
                      full_cov::Bool = false, logdir = "", desc = "", verb = false, est_priors = true, est_cb::Bool = true)
-    full_cov && p.H > 128 && error("full_cov=true is built for H <= 128 (either noise model)")
+    full_cov && p.H > 256 && error("full_cov=true is built for H <= 256 (either noise model)")
     logdir == "" || error("trajectory logging lives in the Python host (data_manip.py)")
     c = sparse_ctx_for(Y, p.H, diag_var; variant = diag_var ? 6 : 4)          # VBMF_VARIANT_TRIAL_DIAGVAR / _TRIAL_DIAG
     hy = Ref(SparseHyper(p.alpha01, p.beta01, p.gamma0, p.delta0, p.eta0, p.zeta0))
