@@ -516,9 +516,31 @@ __global__ __launch_bounds__(T * T) void sparse_cov_b_kernel(double* __restrict_
 }
 
 // flags: bit1 est_cb -> CB/delta, bit2 sigma update, bit3 d + loop bookkeeping (bit4 unused: tr(B'Q) is always st[GX])
+// t2part[b] = this block's share of sum (GA + SigmaA) o (GB + L SigmaB)  (:319): every input is final once the B update's Gram
+// reduction has run, so the 4 x Hp^2 fp64 values (2 MiB at H = 256) are read by T2_BLOCKS workgroups beside the next Y'B pass
+// instead of by sparse_ctrl_end_kernel's single workgroup on the critical path after it (one workgroup pulls ~40 GB/s: 54 us).
+constexpr int T2_BLOCKS = 64;
+__global__ __launch_bounds__(256) void sparse_t2_kernel(const double* __restrict__ st, StateLayout lay, int H, double Lg,
+                                                        double* __restrict__ t2part, const int* __restrict__ ints) {
+    __shared__ double red[16];
+    if (load_stop(ints)) return;
+    const int Hp = lay.Hp;
+    const double* GA = st + lay.GA();
+    const double* GB = st + lay.GB();
+    const double* SA = st + lay.SA();
+    const double* SB = st + lay.SB();
+    const int hsh = 31 - __clz(Hp);                              // Hp is a power of two (32 .. 256)
+    double t2 = 0.0;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < Hp * Hp; t += gridDim.x * blockDim.x)
+        if ((t >> hsh) < H && (t & (Hp - 1)) < H) t2 += (GA[t] + SA[t]) * (GB[t] + Lg * SB[t]);   // SigmaA already summed over m (QS3)
+    t2 = block_sum(t2, red);
+    if (threadIdx.x == 0) t2part[blockIdx.x] = t2;
+}
+
 __global__ __launch_bounds__(1024) void sparse_ctrl_end_kernel(double* __restrict__ st, StateLayout lay, int H,
                                                               double Lg, int flags, double eps,
-                                                              double* __restrict__ trace, int* __restrict__ ints) {
+                                                              double* __restrict__ trace, int* __restrict__ ints,
+                                                              const double* __restrict__ t2part = nullptr) {
     __shared__ double red[16];
     if (load_stop(ints)) return;
     const int Hp = lay.Hp;
@@ -530,10 +552,15 @@ __global__ __launch_bounds__(1024) void sparse_ctrl_end_kernel(double* __restric
     double* cb = st + lay.cb();
     double* scal = st + lay.scal();
     double t2 = 0.0;
-    for (int t = threadIdx.x; t < H * H; t += blockDim.x) {
-        const int i = t / H, j = t - i * H;
-        const long long ij = (long long)i * Hp + j;
-        t2 += (GA[ij] + SA[ij]) * (GB[ij] + Lg * SB[ij]);        // SigmaA already summed over m (QS3)
+    if (t2part != nullptr) {                                     // sparse_t2_kernel's shares, fixed order
+        if (threadIdx.x == 0)
+            for (int b = 0; b < T2_BLOCKS; ++b) t2 += t2part[b];
+    } else {
+        for (int t = threadIdx.x; t < H * H; t += blockDim.x) {
+            const int i = t / H, j = t - i * H;
+            const long long ij = (long long)i * Hp + j;
+            t2 += (GA[ij] + SA[ij]) * (GB[ij] + Lg * SB[ij]);    // SigmaA already summed over m (QS3)
+        }
     }
     t2 = block_sum(t2, red);
     __syncthreads();

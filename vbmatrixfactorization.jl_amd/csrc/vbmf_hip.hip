@@ -88,6 +88,7 @@ struct vbmf_ctx {
     bool full_cov = false;
     bool narrow = false;             // NarrowCfg geometry of the streaming kernel (small problems)
     double* fpart = nullptr;         // per-block sums of Sigma_m
+    double* t2part = nullptr;        // sparse run loops: sparse_t2_kernel's shares of sum (GA + SA) o (GB + L SB)
     double* fws = nullptr;           // full_cov, H > 128: per-workgroup [K | inv(K) | W | S] of the blocked Schur inverse
     int fblocks = 0;
     vbmf_sparse_hyper hyp{};
@@ -979,7 +980,7 @@ int vbmf_destroy(vbmf_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     prof_harvest(c);
     if (c->comm) ncclCommDestroy(c->comm);
-    void* bufs[] = {c->gw, c->hmean, c->fws, c->Y1, c->Y2, c->FA_alloc, c->FB_alloc, c->FD, c->SBf, c->P, c->Q, c->Pred, c->A32, c->B32[0], c->B32[1], c->SA32,
+    void* bufs[] = {c->gw, c->hmean, c->fws, c->t2part, c->Y1, c->Y2, c->FA_alloc, c->FB_alloc, c->FD, c->SBf, c->P, c->Q, c->Pred, c->A32, c->B32[0], c->B32[1], c->SA32,
                     c->SB32, c->gslab, c->st, c->gtmp, c->ypart, c->trpart, c->ints, c->mask, c->dS32, c->CA32, c->beta32, c->vtab,
                     c->sigv, c->zetav, c->yrow, c->hpart, c->vsq, c->sig32, c->G32, c->FBs_alloc, c->gpart, c->fpart};
     for (void* b : bufs) if (b) hipFree(b);
@@ -2043,8 +2044,19 @@ static int dual_update_priors(vbmf_ctx* c) {
     return VBMF_OK;
 }
 
-static int launch_sparse_ctrl_end(vbmf_ctx* c, int flags, double eps, double* trace) {
-    hipLaunchKernelGGL(sparse_ctrl_end_kernel, dim3(1), dim3(c->H > 64 ? 1024 : 256), 0, ctrl_stream(c), c->st, c->lay, (int)c->H, (double)c->Lg, flags, eps, trace, c->ints);
+// t2_ahead: the shares of sum (GA + SA) o (GB + L SB) were left in c->t2part by launch_sparse_t2 (same stream, earlier)
+static int launch_sparse_t2(vbmf_ctx* c) {
+    if (!c->t2part) {
+        HIPCHK(c, hipMalloc((void**)&c->t2part, T2_BLOCKS * 8));
+        HIPCHK(c, hipMemset(c->t2part, 0, T2_BLOCKS * 8));
+    }
+    hipLaunchKernelGGL(sparse_t2_kernel, dim3(T2_BLOCKS), dim3(256), 0, ctrl_stream(c), c->st, c->lay, (int)c->H, (double)c->Lg, c->t2part, c->ints);
+    HIPCHK(c, hipGetLastError());
+    return VBMF_OK;
+}
+static int launch_sparse_ctrl_end(vbmf_ctx* c, int flags, double eps, double* trace, bool t2_ahead = false) {
+    hipLaunchKernelGGL(sparse_ctrl_end_kernel, dim3(1), dim3(c->H > 64 ? 1024 : 256), 0, ctrl_stream(c), c->st, c->lay, (int)c->H, (double)c->Lg, flags, eps, trace, c->ints,
+                       t2_ahead ? (const double*)c->t2part : (const double*)nullptr);
     HIPCHK(c, hipGetLastError());
     return VBMF_OK;
 }
@@ -2252,8 +2264,10 @@ static int sparse_run_impl(vbmf_ctx* c, int64_t niter, double eps, int est_cb, i
         if (rc == VBMF_OK && c->diagvar) rc = do_hetero_sigma(c);
         // lambda_max, CB, sigma, d and the stop test: beside the next sweep's Y'B pass when they run on the side stream
         if (rc == VBMF_OK && side_overlap(c)) rc = side_fork(c);
+        const bool t2_ahead = c->use_side && !c->diagvar;        // (diag_var: no scalar noise update, t2 is not used)
+        if (rc == VBMF_OK && t2_ahead) rc = launch_sparse_t2(c);   // 64 workgroups, before the long lambda_max kernel
         if (rc == VBMF_OK) rc = launch_eig(c, 1, 1);
-        if (rc == VBMF_OK) rc = launch_sparse_ctrl_end(c, flags, eps, trace_dev);
+        if (rc == VBMF_OK) rc = launch_sparse_ctrl_end(c, flags, eps, trace_dev, t2_ahead);
         if (rc == VBMF_OK && c->use_side) rc = side_end(c);
         ++it;
         if (rc == VBMF_OK && (it % 8 == 0 || it == niter)) {
