@@ -365,6 +365,26 @@ def test_full_cov_against_the_oracle(pkg, L, M, H):
         pkg._check_full_cov(True, False, 257)
 
 
+@pytest.mark.parametrize("diag_var", [False, True])
+def test_full_cov_wide_rank_run(pkg, diag_var):
+    """The run loop with full_cov = true at 128 < H <= 256 (one 1024-thread workgroup per column through the blocked Schur inverse
+    in a global workspace), either noise model: 4 sweeps at H = 150, M = 24 against the oracle's dense 3600 x 3600 inverse."""
+    L, M, H = 400, 24, 150
+    if diag_var:
+        Y, po = _mk_hetero(L, M, H, 131, H1=2, labels=[3, 11, 20])
+    else:
+        Y, po = _mk(L, M, H, 131, H1=2, labels=[3, 11, 20])
+    pkg.set_defaults(y_dtype=pkg.VBMF_Y_F32, factor_dtype=pkg.VBMF_FACTOR_AUTO)
+    Yf = Y.astype(np.float32).astype(np.float64)
+    po.trYTY = float(np.sum(Yf * Yf))
+    pg = _to_pkg_hetero(pkg, po) if diag_var else _to_pkg(pkg, po)
+    d_gpu = pkg.vbmf_sparse_(Yf, pg, 4, eps=0.0, full_cov=True, diag_var=diag_var)
+    d_ref, _ = O.vbmf_sparse_(Yf, po, 4, eps=0.0, full_cov=True, diag_var=diag_var)
+    (_cmp_h if diag_var else _cmp)(f"full_cov run4 {L}x{M} H{H} diag_var={diag_var}", pg, po, 2e-3)
+    assert np.any(pg.SigmaA != np.diag(np.diag(pg.SigmaA))) and abs(d_gpu - d_ref) <= 2e-2 * d_ref + 2e-6
+    assert np.all(pg.AHat[[3, 11, 20], H - 2:] == 0.0)
+
+
 def test_lower_bound_trimmed(pkg):
     """lowerBoundTrimmed (src/vbmf_sparse.jl:478-489; examples/mil_util.jl:505): the device masks its M*H-long sums with
     |ATVecHat| > trim; the oracle trims the vectors like the reference and calls lowerBound.  PARITY UNPINNED (no recorded value)."""
