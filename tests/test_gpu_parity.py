@@ -358,6 +358,23 @@ def test_rank_above_128_slow_path(pkg):
     assert abs(pg._last_run[1] - d) <= 2e-2 * d
 
 
+@pytest.mark.parametrize("L,M,H", [(66001, 260, 140), (65700, 300, 96)])
+def test_long_side_wide_rank(pkg, L, M, H):
+    """The LONG-side instantiations of the H >= 128 between-pass kernels (>= 2048 row tiles: post_frag2 with 256 accumulator
+    registers per wave and its read-ahead epilogue, gram_tiles3 with one round of chunks, the ragged last wave) at a rank that is
+    not a multiple of 32 -- the table's padding rows and columns take part in every MFMA -- at a size the oracle still does in
+    seconds.  (The full-size tests cover H = 128 and 256 exactly; the small parity shapes only the short-side instantiations.)"""
+    Y, po = _problem(L, M, H, 700 + H)
+    ydt, fdt, tol = _mode_opts(pkg, "bf16x2")
+    Ys = _stored(pkg, Y, H, ydt, fdt)
+    pkg.set_defaults(y_dtype=ydt, factor_dtype=fdt)
+    pg = to_pkg_params(pkg, po)
+    pkg.vbmf_(Ys, pg, 2, eps=0.0, est_covs=True, est_var=True)
+    _, n, d = O.vbmf_(Ys, po, 2, eps=0.0, est_covs=True, est_var=True)
+    compare(f"bf16x2 {L}x{M} H{H} run2 (long side)", pg, po, {k: 3 * v for k, v in tol.items()})
+    assert pg._last_run[0] == 2 and abs(pg._last_run[1] - d) <= 2e-2 * d + D_ATOL
+
+
 def test_logged_trajectory_against_the_reference_record(pkg, golden_dir, tmp_path):
     """vbmf!(...; logdir=...) (src/vbmf.jl:181-184,205-207,224-228): run the reference's recorded experiment on the
     device with per-sweep logging, read the log back with the data_manip twin and compare EVERY slice with the
