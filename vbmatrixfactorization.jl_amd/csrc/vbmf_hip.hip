@@ -109,6 +109,7 @@ struct vbmf_ctx {
     bool use_side = false, side_pending = false;
     bool in_run = false;              // inside vbmf_run: the control chain rides in workgroups 0-1 of the pass launches
     int gslab_cap = 256;
+    size_t gslab_bytes = 0;           // allocated size of gslab: every Gram launcher checks its slab count against it
     bool xcd_map = true;              // XCD-aware work map for split-K pass launches (env VBMF_XCD_MAP=0 turns it off)
     bool P_frag = false;              // the Y'B product in c->P / c->Pred is fragment-major (stream_gemm.hpp, frag_out)
     bool B32_stale = false;           // the register epilogue skipped the fp32 store of B (inside vbmf_run): tiles are current
@@ -202,6 +203,14 @@ static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline int grid_for(int64_t n, int block = 256, int cap = 8192) {
     return (int)std::max<int64_t>(1, std::min<int64_t>((n + block - 1) / block, cap));
 }
+
+// host-side guard of every launcher that writes Gram partial slabs: `nslab` slabs of `floats` fp32 values must fit c->gslab
+#define GSLAB_CHECK(c, nslab, floats)                                                                                       \
+    do {                                                                                                                    \
+        if ((size_t)(nslab) * (size_t)(floats) * 4 > (c)->gslab_bytes)                                                      \
+            FAIL(c, VBMF_ERR_INVALID, "internal: %lld Gram slabs of %lld floats exceed the slab buffer (%zu bytes) (%s:%d)", \
+                 (long long)(nslab), (long long)(floats), (c)->gslab_bytes, __FILE__, __LINE__);                            \
+    } while (0)
 
 // per-NH geometry of the streaming kernel: NXW * NH accumulator tiles per wave -- 8 (128 registers) up to H = 64,
 // 16 (all 256 AGPRs) from H = 128 on, where the factor operand's L2->L1 traffic per Y byte is what limits a CU
@@ -365,6 +374,7 @@ static int launch_stream(vbmf_ctx* c, int pass, int ctrl_mode = 0, bool epi = fa
         if (c->in_run) c->B32_stale = true;
         if (ctrl_mode) { ca.sready = c->ints + I_SREADY; ca.sready_val = c->sready_seq; }
         if (epi_slabs) *epi_slabs = bps;
+        GSLAB_CHECK(c, bps, 2 * (c->NH * (c->NH + 1) / 2) * 1024);
     }
     const size_t lds = ctrl_mode ? ctrl_lds_bytes(c->NH) : 0;
     prof_begin(c, pass);
@@ -522,6 +532,7 @@ static int launch_post_gram(vbmf_ctx* c, int which, const float* In) {
     const unsigned char* mk = (which == 0 && c->has_mask) ? c->mask : nullptr;
     const int hstart = (int)(c->H - c->H1);
     const int grid = std::min(c->gslab_cap, (d.XT + 3) / 4);
+    GSLAB_CHECK(c, grid, 2 * (c->NH * (c->NH + 1) / 2) * 1024);
     const int* stop = c->ints + I_STOP;
     double* trp = (which == 1 && !c->diagvar) ? c->trpart : nullptr;
     // inside the run loops the fp32 copy of B is not written per sweep: the operand tiles carry the factor (rebuilt once at the end)
@@ -596,6 +607,7 @@ static int launch_gram(vbmf_ctx* c, int which, const float* cur, const float* pr
     // Gram of it is asked for: every producer of the fp32 factor writes them in the same kernel)
     const bool from_tiles = c->NH >= 4 && c->mode != MODE_F32;
     bool pair_slabs = false;
+    GSLAB_CHECK(c, nchunk, 2 * c->Hp * c->Hp);         // dense slabs; pair slabs (upper pairs only) are smaller
     if (from_tiles) {
         const uint4* Ft = which == 0 ? c->FA : c->FB;
         // delta-Gram: a plain tile Gram of the delta tiles the post kernel left (two parts: hi + lo) -- or, without them
@@ -1107,13 +1119,17 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
     ALLOC(c->B32[1], (size_t)c->Lp * c->Hp * 4);
     ALLOC(c->SA32, (size_t)c->Hp * c->Hp * 4);
     ALLOC(c->SB32, (size_t)c->Hp * c->Hp * 4);
-    const int nchunk = std::max(cdiv(c->d1.XT, gram_tiles_per_chunk(c, 0)), cdiv(c->d2.XT, gram_tiles_per_chunk(c, 1)));
+    // every chunking any Gram launcher can use: the per-side choice of gram_tiles_per_chunk() AND the context-wide
+    // tiles_per_chunk of the dense-slab kernel (weighted_gram_B of full_cov + diag_var runs it in every storage mode)
+    const int nchunk = std::max(std::max(cdiv(c->d1.XT, gram_tiles_per_chunk(c, 0)), cdiv(c->d2.XT, gram_tiles_per_chunk(c, 1))),
+                                std::max(cdiv(c->d1.XT, c->tiles_per_chunk), cdiv(c->d2.XT, c->tiles_per_chunk)));
     // Gram partial slabs: one per chunk (generic path), per post_gram workgroup (<= 256), or per pass-2 workgroup when the
     // pass carries the register epilogue (capped at 1024 slabs = 24 MB; longer shards use the separate post kernel)
     {
         const int epi_blocks = (c->NH <= 2) ? std::min(1024, (c->d2.XT / nxw_of(c->NH) + 3) / 4) : 0;
         c->gslab_cap = std::max(256, epi_blocks);
-        ALLOC(c->gslab, std::max((size_t)nchunk * 2 * c->Hp * c->Hp * 4, (size_t)c->gslab_cap * 2 * 3 * 1024 * 4));
+        c->gslab_bytes = std::max((size_t)nchunk * 2 * c->Hp * c->Hp * 4, (size_t)c->gslab_cap * 2 * 3 * 1024 * 4);
+        ALLOC(c->gslab, c->gslab_bytes);
     }
     ALLOC(c->st, (size_t)c->lay.total() * 8);
     ALLOC(c->gtmp, ((size_t)2 * c->Hp * c->Hp + 8) * 8);
@@ -1884,9 +1900,12 @@ static int weighted_gram_B(vbmf_ctx* c, const double** out) {
     const long long nel = (long long)c->Lp * c->Hp;
     hipLaunchKernelGGL(sqrt_rowscale_kernel, dim3(grid_for(nel, 256, 4096)), dim3(256), 0, c->stream, c->B32[c->bcur], c->sig32, scratch,
                        nel, c->Hp, stop);
+    // the dense-slab kernel with the context-wide chunk size (NOT gram_tiles_per_chunk(): that is the tile kernels' choice and
+    // gives fewer, larger chunks on some shapes); vbmf_create sizes gslab for this chunking too, and the guard below says so
     const int tpc = c->tiles_per_chunk;
     const int nchunk = cdiv(c->d2.XT, tpc);
     const int nw = nchunk * c->NH * c->NH;
+    GSLAB_CHECK(c, nchunk, 2 * c->Hp * c->Hp);
     DISPATCH_NH(c->NH, {
         hipLaunchKernelGGL((gram_kernel<NHc>), dim3((nw + 3) / 4), dim3(256), 0, c->stream, scratch, (const float*)nullptr, c->gslab, c->d2.XT,
                            tpc, nchunk, stop);
