@@ -47,7 +47,9 @@ typedef enum {
 #define VBMF_Y_BF16 1          /* Y bf16, v_mfma_f32_32x32x16_bf16, fp32 accumulate */
 /* factor operand (BHat in Y'B, AHat in Y*A) fed to the MFMA */
 #define VBMF_FACTOR_AUTO 0     /* f32 with f32 Y; bf16x2 with bf16 Y */
-#define VBMF_FACTOR_BF16 1     /* one bf16 rounding of the factor */
+#define VBMF_FACTOR_BF16 1     /* one bf16 rounding of the factor: ~3 significant digits in A/B, sigma2 only loosely (a speed
+                                  option, not a parity mode); vbmf_create returns VBMF_ERR_UNSUPPORTED for H > VBMF_FACTOR_BF16_MAX_H */
+#define VBMF_FACTOR_BF16_MAX_H 128
 #define VBMF_FACTOR_BF16X2 2   /* hi+lo bf16 split (two MFMAs), ~16 mantissa bits */
 
 #define VBMF_VARIANT_BASIC 0        /* src/vbmf.jl */

@@ -142,6 +142,19 @@ static unsigned long long diff_words(const float* a, const float* b, size_t n) {
     return h;
 }
 
+__global__ void k_maxdiff(const float* a, const float* b, size_t n, unsigned* out) {     // out[0] = max |a - b|, out[1] = max |a| (as bits of non-negative floats)
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float d = 0.f, m = 0.f;
+    for (; i < n; i += (size_t)gridDim.x * blockDim.x) { d = fmaxf(d, fabsf(a[i] - b[i])); m = fmaxf(m, fabsf(a[i])); }
+    atomicMax(out, __float_as_uint(d)); atomicMax(out + 1, __float_as_uint(m));
+}
+static void max_diff(const float* a, const float* b, size_t n, float* d, float* m) {
+    unsigned* o; CK(hipMalloc(&o, 8)); CK(hipMemset(o, 0, 8));
+    hipLaunchKernelGGL(k_maxdiff, dim3(1024), dim3(256), 0, 0, a, b, n, o);
+    unsigned h[2]; CK(hipMemcpy(h, o, 8, hipMemcpyDeviceToHost)); CK(hipFree(o));
+    memcpy(d, &h[0], 4); memcpy(m, &h[1], 4);
+}
+
 struct Shape { long long X, K; int H; int ns; const char* name; };
 
 // current library kernel (fragment-major output) vs the re-shaped wave tile, same decomposition, interleaved rounds
@@ -199,10 +212,50 @@ static void run_lds(const Shape& sh, const uint4* Y, const uint4* F, float* O, s
     fflush(stdout);
 }
 
+template __global__ void vbmf::stream_lds8x_kernel<8, 0, 2>(const uint4*, const uint4*, float*, int, int, int, int, long long, int);
+template __global__ void vbmf::stream_lds8x_kernel<4, 0, 2>(const uint4*, const uint4*, float*, int, int, int, int, long long, int);
+template __global__ void vbmf::stream_lds8x_kernel<8, 1, 2>(const uint4*, const uint4*, float*, int, int, int, int, long long, int);
+template __global__ void vbmf::stream_lds8x_kernel<4, 1, 2>(const uint4*, const uint4*, float*, int, int, int, int, long long, int);
+
+// the 8-wave LDS-DMA kernel against the library kernel at the same decomposition, interleaved rounds, bit-compared
+template <int NH, int NXW, int DY, int DF, int SHAPE>
+static void run_lds8(const Shape& sh, const uint4* Y, const uint4* F, float* O, size_t obytes) {
+    const int XT = (int)(((sh.X + 31) / 32 + NXW - 1) / NXW * NXW);
+    const int ns = sh.ns;
+    const int KS0 = (int)((sh.K + 15) / 16);
+    int sps = (KS0 + ns - 1) / ns; sps = (sps + 11) / 12 * 12;
+    const int KS = sps * ns;
+    const long long ld = (long long)XT * 32;
+    const size_t n = (size_t)ns * NH * 32 * ld;
+    if (2 * n * 4 > obytes) { printf("  (output too large)\n"); return; }
+    float* O2 = O + n;
+    CtrlArgs ca{}; ca.mode = 0;
+    EpiArgs ea{}; ea.frag_out = 1;
+    const int XG = XT / NXW, bps = (XG + 3) / 4;
+    constexpr int XPW = 8 / (NH / 4);
+    const int lbps = (XT / 2 + XPW - 1) / XPW;
+    const int lds = 6 * 24 * 1024;
+    CK(hipFuncSetAttribute((const void*)stream_lds8x_kernel<NH, SHAPE, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    const double flop = 2.0 * sh.X * sh.K * sh.H * 2.0, yb = (double)sh.X * sh.K * 2.0;
+    auto cur = [&] { hipLaunchKernelGGL((stream_gemm_kernel<2, NH, NXW, DY, DF, 0>), dim3(bps * ns), dim3(256), 0, 0, Y, F, O, XG, KS, sps, ns, ld, (const int*)nullptr, ca, 0, ea); };
+    auto l8 = [&] { hipLaunchKernelGGL((stream_lds8x_kernel<NH, SHAPE, 2>), dim3(lbps * ns), dim3(512), lds, 0, Y, F, O2, XT, KS, sps, ns, ld, 1); };
+    CK(hipMemset(O, 0xff, n * 4)); CK(hipMemset(O2, 0xee, n * 4));
+    double tc[3], tp[3];
+    for (int r = 0; r < 3; ++r) { tc[r] = time_ms(cur, 6); tp[r] = time_ms(l8, 6); }
+    std::sort(tc, tc + 3); std::sort(tp, tp + 3);
+    const unsigned long long dw = diff_words(O, O2, n);
+    float md = 0.f, mm = 0.f; max_diff(O, O2, n, &md, &mm);
+    printf("  library  NXW%d x NH%d DY%d DF%d  blocks %4d: median %.3f ms (min %.3f)  %.0f GB/s of Y  %.0f TFLOP/s (hi+lo)\n", NXW, NH, DY, DF, bps * ns, tc[1], tc[0], yb / tc[1] / 1e6, flop / tc[1] / 1e9);
+    printf("  lds8     shape %d, 8 waves x 2x4 tiles blocks %4d: median %.3f ms (min %.3f)  %.0f GB/s of Y  %.0f TFLOP/s (hi+lo)   differing words %llu of %zu, max |diff| %.3g of max |value| %.3g\n", SHAPE, lbps * ns, tp[1], tp[0],
+           yb / tp[1] / 1e6, flop / tp[1] / 1e9, dw, n, md, mm);
+    fflush(stdout);
+}
+
 int main(int argc, char** argv) {
     const char* what = argc > 1 ? argv[1] : "all";
     const bool do_bare = !strcmp(what, "all") || !strcmp(what, "bare");
     const bool do_stream = !strcmp(what, "all") || !strcmp(what, "stream");
+    const bool do_lds8 = !strcmp(what, "all") || !strcmp(what, "lds8");
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
     printf("device %s, %d CUs, clockRate %d kHz\n", prop.gcnArchName, prop.multiProcessorCount, prop.clockRate);
     if (do_bare) {
@@ -222,7 +275,7 @@ int main(int argc, char** argv) {
         run_bare<1, 4, 16>(opnd, out, stamps, "16x16x32, 1 wave/SIMD, zeros", 256);
         CK(hipFree(opnd)); CK(hipFree(out)); CK(hipFree(stamps));
     }
-    if (do_stream) {
+    if (do_stream || do_lds8) {
         Shape shapes[] = {{10000, 100000, 256, 12, "cfg5 pass1 (x=M=10k, k=L=100k, H=256), 12 k-slices"},
                           {100000, 10000, 256, 1, "cfg5 pass2 (x=L=100k, k=M=10k, H=256)"},
                           {10000, 125000, 128, 12, "cfg4/8 pass1 (x=M=10k, k=L=125k, H=128), 12 k-slices"},
@@ -236,6 +289,11 @@ int main(int argc, char** argv) {
         for (int si = 0; si < 4; ++si) {
             const Shape& sh = shapes[si];
             printf("== (B) %s\n", sh.name);
+            if (do_lds8) {
+                if (sh.H == 256) { run_lds8<8, 2, 2, 2, 0>(sh, Y, F, O, obytes); run_lds8<8, 2, 2, 2, 1>(sh, Y, F, O, obytes); }
+                else { run_lds8<4, 4, 4, 2, 0>(sh, Y, F, O, obytes); run_lds8<4, 4, 4, 2, 1>(sh, Y, F, O, obytes); }
+            }
+            if (!do_stream) continue;
             if (sh.H == 256) {
                 run_stream<8, 2, 2, 2, 4, 4, 2, 2>(sh, Y, F, O, obytes);
                 run_stream<8, 2, 2, 2, 4, 4, 4, 2>(sh, Y, F, O, obytes);

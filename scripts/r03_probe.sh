@@ -6,11 +6,11 @@ tag=${1:-a}
 R=${GRAFT_REPO_ROOT:-$PWD}
 out=$R/gpurun_out/r03_probe_$tag
 mkdir -p $out
-$R/scripts/r03_probe.bin all > $out/probe.txt 2>&1 || { echo "probe failed"; tail -20 $out/probe.txt; exit 1; }
+$R/scripts/r03_probe.bin ${2:-all} > $out/probe.txt 2>&1 || { echo "probe failed"; tail -20 $out/probe.txt; exit 1; }
 cat $out/probe.txt
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES \
-  --kernel-trace --output-format csv -d $out/pmc -- $R/scripts/r03_probe.bin stream > $out/pmc.log 2>&1 || { echo "rocprofv3 failed"; tail -5 $out/pmc.log; exit 1; }
+  --kernel-trace --output-format csv -d $out/pmc -- $R/scripts/r03_probe.bin ${3:-stream} > $out/pmc.log 2>&1 || { echo "rocprofv3 failed"; tail -5 $out/pmc.log; exit 1; }
 python3 - <<PY
 import csv, glob, collections, json, os
 out="$out"

@@ -112,10 +112,13 @@ def test_run_three_sweeps(pkg, mode, L, M, H):
     """vbmf! for 3 sweeps (est_covs=est_var=true) on rank-deficient toy data, every field compared."""
     if mode == "bf16" and H > 128:
         # single-bf16 factors carry ~3 digits; with 200 columns on rank-8 data the residual ||Y||^2 - 2tr + tr(...) (a 1e-3
-        # cancellation) falls below that noise, sigma2 comes out 157x off after three sweeps and takes the factors with it --
-        # measured identically before and after this round's H >= 128 kernels.  The mode is a speed option for well-posed
-        # ranks (documented in DESIGN.md); hi + lo ("bf16x2", the default) and fp32 are the parity modes at this rank.
-        pytest.skip("single-bf16 factor mode loses sigma2 at H = 200 on rank-8 data (by design of the mode)")
+        # cancellation) falls below that noise and sigma2 came out 157x off after three sweeps (round 2).  The library now
+        # REFUSES the mode above H = 128 (include/vbmf_hip.h, VBMF_FACTOR_BF16_MAX_H) instead of returning that result.
+        with pytest.raises(pkg.VbmfError) as ei:
+            pkg.capi.Context(L, M, H, y_dtype=pkg.VBMF_Y_BF16, factor_dtype=pkg.VBMF_FACTOR_BF16)
+        assert ei.value.code == pkg.capi.VBMF_ERR_UNSUPPORTED, ei.value
+        assert "VBMF_FACTOR_BF16" in str(ei.value)
+        return
     Y, po = _problem(L, M, H, 300 + H)
     ydt, fdt, tol = _mode_opts(pkg, mode)
     Ys = _stored(pkg, Y, H, ydt, fdt)

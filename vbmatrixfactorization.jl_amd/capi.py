@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("VBMF_HIP_LIB") or os.path.join(_HERE, "libvbmf_hip.so
 
 VBMF_Y_F32, VBMF_Y_BF16 = 0, 1
 VBMF_FACTOR_AUTO, VBMF_FACTOR_BF16, VBMF_FACTOR_BF16X2 = 0, 1, 2
+VBMF_FACTOR_BF16_MAX_H = 128      # vbmf_create refuses the single-bf16 factor operand above this rank (include/vbmf_hip.h)
 VBMF_VARIANT_BASIC, VBMF_VARIANT_SPARSE_DIAG, VBMF_VARIANT_SPARSE_DIAGVAR, VBMF_VARIANT_DUAL_DIAG, VBMF_VARIANT_TRIAL_DIAG = 0, 1, 2, 3, 4
 VBMF_VARIANT_DUAL_DIAGVAR, VBMF_VARIANT_TRIAL_DIAGVAR = 5, 6
 VBMF_COMPAT_SPECTRAL_DELTA, VBMF_COMPAT_SPARSE_REPEAT, VBMF_COMPAT_DEFAULT = 1, 2, 0xFFFFFFFF

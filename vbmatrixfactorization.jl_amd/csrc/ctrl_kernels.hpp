@@ -41,9 +41,14 @@ enum : int { S_SIGMA2 = 0, S_TRYY, S_LOGDET_SA, S_LOGDET_SB, S_LAMB_PREV, S_LAMB
              S_LOGDET_SA_SHADOW = 20 };      // 12..18: sparse_kernels.hpp
 enum : int { I_STOP = 0, I_ITERS = 1, I_ERR = 2, I_NITER = 3, I_SREADY = 4 };
 
+// Threads of the workgroup that run the control algebra: the whole block -- except in the 512-thread launch of the H >= 128
+// streaming kernel (stream_gemm.hpp, stream_lds8_kernel), whose control workgroups run on their first 256 threads (waves 4-7
+// leave at once; a barrier counts live waves only).  No control kernel of its own is ever launched with 512 threads.
+__device__ __forceinline__ int ctrl_nthreads() { return blockDim.x == 512u ? 256 : (int)blockDim.x; }
+
 __device__ __forceinline__ double block_sum(double v, double* red) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-    const int nw = (blockDim.x + 63) >> 6;
+    const int nw = (ctrl_nthreads() + 63) >> 6;
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
@@ -53,7 +58,7 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
 }
 __device__ __forceinline__ double block_max(double v, double* red) {
     for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off));
-    const int nw = (blockDim.x + 63) >> 6;
+    const int nw = (ctrl_nthreads() + 63) >> 6;
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
@@ -73,12 +78,12 @@ __device__ inline double gj_inverse_spd(double* W, int n, double* aux, int* err)
         if (!(piv > 0.0) || !isfinite(piv)) { if (threadIdx.x == 0) atomicExch(err, 1); }
         const double pinv = 1.0 / piv;
         logdet += log(piv);
-        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        for (int i = threadIdx.x; i < n; i += ctrl_nthreads()) {
             colk[i] = W[(long long)i * n + k];
             rowk[i] = (i == k ? 1.0 : W[(long long)k * n + i]) * pinv;
         }
         __syncthreads();
-        for (int t = threadIdx.x; t < n * n; t += blockDim.x) {
+        for (int t = threadIdx.x; t < n * n; t += ctrl_nthreads()) {
             const int i = t / n, j = t - i * n;
             double v;
             if (i == k) v = rowk[j];
@@ -420,7 +425,7 @@ __device__ __forceinline__ void ctrl_cov_dev(double* __restrict__ st, StateLayou
     __syncthreads();
     double ld = 0.0;
     int bad = 0;
-    for (int k = threadIdx.x; k < H; k += blockDim.x) {
+    for (int k = threadIdx.x; k < H; k += ctrl_nthreads()) {
         const double pv = pivs[k];
         if (!(pv > 0.0) || !isfinite(pv)) bad = 1;
         ld += log(pv);
@@ -470,7 +475,7 @@ __device__ __forceinline__ void eig_dev(double* __restrict__ st, StateLayout lay
     const double* G = st + (which == 0 ? lay.GD() : lay.GB());
     double* scal = st + lay.scal();
     double tr = 0.0;
-    for (int i = threadIdx.x; i < H; i += blockDim.x) tr += G[(long long)i * Hp + i];
+    for (int i = threadIdx.x; i < H; i += ctrl_nthreads()) tr += G[(long long)i * Hp + i];
     tr = block_sum(tr, red);
     if (!spectral || !(tr > 0.0) || !isfinite(tr)) {        // zero matrix -> 0; NaN propagates (loop exit on NaN d)
         if (threadIdx.x == 0) scal[slot] = tr;
@@ -482,7 +487,7 @@ __device__ __forceinline__ void eig_dev(double* __restrict__ st, StateLayout lay
     float* A0 = ldsf;
     float* A1 = ldsf + NP * LD;
     const int tx = threadIdx.x % T, ty = threadIdx.x / T;
-    for (int t = threadIdx.x; t < NP * NP; t += blockDim.x) {
+    for (int t = threadIdx.x; t < NP * NP; t += ctrl_nthreads()) {
         const int i = t / NP, j = t - i * NP;
         A0[i * LD + j] = (i < H && j < H) ? (float)(G[(long long)i * Hp + j] / tr) : 0.f;   // |G_ij| <= tr: no overflow
     }
@@ -590,7 +595,7 @@ __global__ __launch_bounds__(1024) void eig_power_kernel(double* __restrict__ st
     double* scal = st + lay.scal();
     const int slot = which == 0 ? S_LAMD : S_LAMB_NEW;
     double tr = 0.0;
-    for (int i = threadIdx.x; i < H; i += blockDim.x) tr += G[(long long)i * Hp + i];
+    for (int i = threadIdx.x; i < H; i += ctrl_nthreads()) tr += G[(long long)i * Hp + i];
     tr = block_sum(tr, red);
     if (!spectral || !(tr > 0.0) || !isfinite(tr)) {
         if (threadIdx.x == 0) scal[slot] = tr;
@@ -670,7 +675,7 @@ __device__ __forceinline__ void ctrl_end_dev(double* __restrict__ st, StateLayou
     // that value does not count as "stopped" here -- whichever of the two workgroups gets there first.
     int stopped = load_stop(ints);
     if ((flags & 64) && stopped == it_row + 1) stopped = 0;
-    const int hme = threadIdx.x;                                 // H <= 256 <= blockDim.x: one diagonal entry per thread
+    const int hme = threadIdx.x;                                 // H <= 256 <= ctrl_nthreads(): one diagonal entry per thread
     const double scv = hme < 32 ? scal[hme] : 0.0;
     const double trdot = st[lay.GX()];                           // tr(Y'BA') = sum (Y A) o BHat, summed where BHat was produced
     double ca_h = hme < H ? ca[hme] : 1.0, cb_h = hme < H ? cb[hme] : 1.0;
@@ -680,11 +685,11 @@ __device__ __forceinline__ void ctrl_end_dev(double* __restrict__ st, StateLayou
     {
         constexpr int U = 8;
         const int sh = 31 - __clz(Hp), total = Hp * Hp;          // Hp is a power of two
-        for (int e0 = threadIdx.x; e0 < total; e0 += U * blockDim.x) {
+        for (int e0 = threadIdx.x; e0 < total; e0 += U * ctrl_nthreads()) {
             double gb[U], ga[U], sa[U], sb[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int e = e0 + u * blockDim.x;
+                const int e = e0 + u * ctrl_nthreads();
                 const bool ok = e < total && (e >> sh) < H && (e & (Hp - 1)) < H;
                 const int ee = ok ? e : 0;
                 gb[u] = GB[ee]; ga[u] = GA[ee]; sa[u] = SA[ee]; sb[u] = SB[ee];
@@ -692,7 +697,7 @@ __device__ __forceinline__ void ctrl_end_dev(double* __restrict__ st, StateLayou
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int e = e0 + u * blockDim.x;
+                const int e = e0 + u * ctrl_nthreads();
                 const int i = e >> sh, j = e & (Hp - 1);
                 if (e < total && i == j && i < H) { dg[0][i] = ga[u]; dg[1][i] = sa[u]; dg[2][i] = gb[u]; dg[3][i] = sb[u]; }
                 t2 += (ga[u] + M * sa[u]) * (gb[u] + Lg * sb[u]);

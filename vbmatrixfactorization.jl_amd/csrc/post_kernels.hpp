@@ -11,7 +11,7 @@
 //                   Accumulator tiles are fed back as both MFMA operands (sum over the row index
 //                   that lives in registers), so no transpose is needed.
 //   reduce kernels  fp64 reduction of per-chunk Gram slabs; fp32 sum of split-K slabs.
-//   dot_kernel      sum_{x,h} In[h][x]*Fac[x][h]  (tr(Y'BA') when the Gram identity is unavailable).
+//   dot_kernel      per-workgroup shares of sum_{x,h} In[h][x]*Fac[x][h]  (tr(Y'BA') outside a B update), folded in fixed order.
 #pragma once
 #include "common.hpp"
 
@@ -1421,7 +1421,8 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* slabs, int n
     }
 }
 
-// *out += sum_{x<X, h<Hp} (sum_s In[s][h][x]) * Fac[x][h]
+// part[block] = this workgroup's share of  sum_{x<X, h<Hp} (sum_s In[s][h][x]) * Fac[x][h]   (fp64; the caller folds the
+// shares in fixed order with sum_partials_kernel: no atomics, so tr(Y'BA') is the same number on every run and rank)
 // index of element (h, x) of a fragment-major product (stream_gemm.hpp, frag_out)
 __device__ __forceinline__ long long frag_index(int h, long long x, int NH) {
     const int hr = h & 31, half = (hr >> 2) & 1, r = (hr & 3) + 4 * (hr >> 3);          // rho(r, half) == hr
@@ -1430,7 +1431,7 @@ __device__ __forceinline__ long long frag_index(int h, long long x, int NH) {
 // frag_nh > 0: In is fragment-major with frag_nh = Hp / 32 column tiles
 __global__ __launch_bounds__(256) void dot_kernel(const float* __restrict__ In, long long ldIn, int nslab,
                                                   long long slabStride, const float* __restrict__ Fac, int Hp,
-                                                  long long X, double* __restrict__ out, int frag_nh) {
+                                                  long long X, double* __restrict__ part, int frag_nh) {
     double acc = 0.0;
     for (long long x = (long long)blockIdx.x * blockDim.x + threadIdx.x; x < X;
          x += (long long)gridDim.x * blockDim.x) {
@@ -1442,10 +1443,10 @@ __global__ __launch_bounds__(256) void dot_kernel(const float* __restrict__ In, 
         }
     }
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
-    __shared__ double part[4];
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __shared__ double wsum[4];
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+    if (threadIdx.x == 0) part[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
 }
 
 // dst[i] = src[i] unless the sweep loop has stopped (keeps the state frozen after `stop`)

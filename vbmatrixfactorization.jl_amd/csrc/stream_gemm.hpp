@@ -377,4 +377,245 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const uint4* __restric
     }
 }
 
+// ===========================================================================================================================
+// stream_lds8_kernel -- the H >= 128 streaming contraction (bf16x2 operands): 512-thread workgroups (two waves per SIMD),
+// EVERY operand through LDS, filled by LDS-DMA (buffer_load ... lds: no VGPR destination, 1 KiB per wave-instruction).
+//
+// Why (round 3, profiles/r03_a_mfma_ceiling_probe.txt, r03_a_pmc_mfma_probe.json, r03_c_lds8_probe.txt): these passes are
+// MFMA-bound (hi + lo factor parts), and a bare 32x32x16 loop on random operands sustains 1.82 PFLOP/s here (1.80 GHz under the
+// chip's power management, matrix pipe 100 % busy; the 16x16x32 shape 2.06 PFLOP/s at 2.06 GHz).  The per-wave kernel above
+// sat at 1.08-1.2 PFLOP/s with the pipe 56-63 % busy and its waves issue-stalled 70-75 % of their cycles: every
+// buffer_load_dwordx4 costs the issuing wave ~50 cycles during which it issues no MFMA (H = 256: 18 loads per 32 MFMAs -> 1817
+// cycles per k-step instead of 1024; with a 4 x 4 wave tile 12 loads -> 1625), and at one wave per SIMD nobody else feeds the
+// pipe.  Here a wave issues 3 DMA loads per 16 MFMAs' worth of work, its operand reads are ds_read_b128 (~1.5 cycles of
+// issue each), and the partner wave on the SIMD issues MFMAs meanwhile: pipe 66-74 % busy, 17 % fewer cycles; the chip answers
+// with a lower clock (1.76 instead of 1.92 GHz), so the time gain is 8-11 %, and the 16x16x32 shape -- less accumulator traffic
+// per flop, a higher sustained clock -- gives 4-7 % more: H = 256 0.755 / 0.799 ms against 0.88 / 0.945 ms per pass, H = 128
+// 0.522 / 0.509 against 0.565 / 0.520.
+//
+// Geometry: wave tile = 2 x tiles x 4 h tiles (8 accumulator tiles, 128 registers).  H = 256: the 8 waves are 4 x pairs x 2 h
+// halves (workgroup = 8 x tiles), H = 128: 8 x pairs (16 x tiles) -- the footprints of the per-wave kernel, so the host's plan
+// (block counts, split-K, padding quanta) is unchanged.  Either way a k-step is 24 one-KiB pieces (NF factor fragments + the
+// workgroup's Y tiles), 3 per wave.  LDS: 6 k-step slots = 3 stages of 2 k-steps = 144 KiB, one workgroup per CU.
+// Pipeline: one raw s_barrier per stage; the pieces of stage s+2 are issued while stage s is consumed (two stages = 4 k-steps
+// ~ 2 us in flight); a wave waits for its OWN pieces of stage s with a counted vmcnt and the barrier makes everybody's visible
+// (LDS-DMA data is ordered for a ds_read only by the issuing wave's vmcnt followed by a barrier the reader has passed); the same
+// barrier says every wave is done reading stage s-1, whose slots the new pieces overwrite.  No plain (VGPR-destination) load
+// exists in the loop: beside LDS-DMA hipcc would wait vmcnt(0) at every use of one.  Fragments are lane-linear in HBM
+// already, so the LDS image is a plain copy and every ds_read_b128 is conflict-free; the run-ahead past a split's end lands
+// in the next split's tiles or the buffers' PIPE_D slack and is never consumed.
+// MFMA shape: v_mfma_f32_16x16x32_bf16 over the stage's two k-steps.  A 16x16x32 operand is 16 rows x 32 k = lane (q, r):
+// k group q, row r; k group q <-> (k-step q & 1 of the stage, lane half q >> 1 of the 32x32x16 fragment), the same assignment
+// on both operands so the products pair up, which makes the operand of sub-tile xi a 16-byte read at the per-lane offset
+// (q & 1) * SLOT + ((q >> 1) * 32 + 16 xi + r) * 16 of the unchanged image (rows of 16 lanes stay 256 contiguous bytes:
+// conflict-free).  The 16 x 16 accumulators are converted to the 32 x 32 tile layout of common.hpp at the end
+// (v_permlane16_swap + v_permlane32_swap), so every consumer sees the layouts it always saw.  Against the 32x32x16 kernel the
+// results differ by fp32 summation order only (measured 1.5e-6 of the largest element); they are deterministic.
+// Workgroups 0 and 1 may run the sweep's control chain on their first 256 threads (ctrl_kernels.hpp, ctrl_nthreads()).
+
+// one 1 KiB LDS-DMA piece: 64 lanes x 16 bytes from (descriptor, lane * 16 + soff) to lds + lane * 16 (lds wave-uniform).
+// (Plain functions, not inside the kernel template: with the address-space cast in the template's lambda hipcc (ROCm 7.2)
+// silently drops the HOST-side instantiation of the kernel -- no diagnostic, the launch stub is simply missing at link time.)
+__device__ __forceinline__ void lds_dma_piece(__amdgpu_buffer_rsrc_t r, unsigned char* lds, int voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+}
+__device__ __forceinline__ void lds_dma_piece_nt(__amdgpu_buffer_rsrc_t r, unsigned char* lds, int voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 2);
+}
+
+constexpr int LDS8_SLOT_BYTES = 24 * 1024;            // one k-step: NF factor fragments + the workgroup's Y tiles
+constexpr int LDS8_BYTES = 6 * LDS8_SLOT_BYTES;       // dynamic LDS of a launch (>= the control chain's need, ctrl_lds_bytes)
+
+template <int NH, int RCTRL>
+__global__ __launch_bounds__(512) void stream_lds8_kernel(const uint4* __restrict__ Yt,   // [XT][KS][64]
+                                                          const uint4* __restrict__ Ft,   // [KS][2][NH][64]
+                                                          float* __restrict__ Out,        // [nsplit][NH*32][ldOut] or fragment-major
+                                                          int XT, int KS, int steps_per_split, int nsplit, long long ldOut,
+                                                          const int* __restrict__ stop, CtrlArgs ctrl, int xcd_xb, int frag_out) {
+    constexpr int NF = 2 * NH;
+    constexpr int HS = NH / 4;                 // waves that share an x pair (h slices of 4 tiles)
+    constexpr int XPW = 8 / HS;                // x pairs per workgroup
+    constexpr int YT = 2 * XPW;                // Y tiles per workgroup
+    constexpr int SLOT = (NF + YT) * 1024;     // bytes of one k-step
+    constexpr int NYD = 2 / HS;                // Y pieces this wave fetches per k-step
+    constexpr int NFD = NF / 8;                // factor pieces this wave fetches per k-step
+    constexpr int NDMA = NYD + NFD;            // = 3
+    static_assert(NH == 4 || NH == 8, "wave tile is 2 x 4 tiles");
+    static_assert(SLOT == LDS8_SLOT_BYTES && NDMA == 3, "slot layout");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    int bid = blockIdx.x;
+    if (ctrl.mode != 0) {                                 // launch carries two control workgroups (dispatched first)
+        if (bid < 2) {
+            if constexpr (RCTRL > 0) {
+                if (threadIdx.x < 256) ctrl_chain<RCTRL>(ctrl, smem, bid);
+            }
+            return;
+        }
+        bid -= 2;
+    }
+    if (stop && *stop) return;
+
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int npair = XT >> 1;
+    const int bps = (npair + XPW - 1) / XPW;
+    int split, xb;
+    if (xcd_xb > 0) {                                     // XCD-aware map for split-K launches (see stream_gemm_kernel)
+        const int g = bid & 7, j = bid >> 3;
+        const int w = g * xcd_xb + j;
+        if (j >= xcd_xb || w >= bps * nsplit) return;
+        split = w / bps;
+        xb = w % bps;
+    } else {
+        split = bid / bps;
+        xb = bid % bps;
+    }
+    if (split >= nsplit) return;                          // workgroup-uniform
+    const int xp = wib / HS, hs = wib % HS;
+    const int pair = xb * XPW + xp;
+    const bool active = pair < npair;
+    const int tile0 = (active ? pair : npair - 1) * 2;    // a wave without a pair streams the last one again (it still feeds the ring)
+
+    const long long ks0 = (long long)split * steps_per_split;
+    const unsigned ybytes = (unsigned)(steps_per_split + PIPE_D) * 1024u;
+    const unsigned fbytes = (unsigned)(steps_per_split + PIPE_D) * (NF * 1024u);
+    __amdgpu_buffer_rsrc_t yr[NYD];
+#pragma unroll
+    for (int i = 0; i < NYD; ++i)
+        yr[i] = __builtin_amdgcn_make_buffer_rsrc((void*)(Yt + (((long long)(tile0 + (HS == 2 ? hs : i))) * KS + ks0) * 64), 0, ybytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc((void*)(Ft + ks0 * (NF * 64) + wib * (NFD * 64)), 0, fbytes, 0x00020000);
+    const int voff = lane * 16;
+    // this wave's pieces of k-step `step` into slot `slot`
+    auto dma_step = [&](int step, int slot) __attribute__((always_inline)) {
+        unsigned char* base = smem + slot * SLOT;
+#pragma unroll
+        for (int q = 0; q < NFD; ++q) lds_dma_piece(fr, base + (wib * NFD + q) * 1024, voff, (step * NF + q) * 1024);
+#pragma unroll
+        for (int i = 0; i < NYD; ++i) {
+            unsigned char* dst = base + (NF + xp * 2 + (HS == 2 ? hs : i)) * 1024;
+            if constexpr (Y_AUX == 2) lds_dma_piece_nt(yr[i], dst, voff, step * 1024);
+            else lds_dma_piece(yr[i], dst, voff, step * 1024);
+        }
+    };
+
+    f32x4 acq[2][4][2][2];                     // [tx][th][hi][xi] 16 x 16 tiles
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acq[i][h][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int q16 = lane >> 4, r16 = lane & 15;
+    const int lo16 = (q16 & 1) * SLOT + ((q16 >> 1) * 32 + r16) * 16;      // (+ 256: the upper 16 rows of a 32-wide tile)
+
+    const int nst = steps_per_split >> 1;      // stages of two k-steps (the host pads k-steps to an even count)
+    dma_step(0, 0); dma_step(1, 1); dma_step(2, 2); dma_step(3, 3);
+
+    for (int st0 = 0; st0 < nst; st0 += 3) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int st = st0 + u;
+            if (st >= nst) break;              // wave-uniform
+            // my pieces of stage st have landed (those of stage st + 1 may still be in flight) ...
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
+            // ... and after the barrier everybody's have; every wave is also done reading stage st - 1, whose slots are refilled now
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            // both k-steps of the stage at once: 4 Y + 16 factor operands, 64 MFMAs.  The first operands cannot be requested
+            // before the barrier (exposed LDS latency, once per stage); the factor's lo part is requested between the MFMAs of the
+            // hi part, and the pieces of stage st + 2 go out between the MFMAs as well (one DMA costs its wave ~50-60 cycles of
+            // issue, which the partner wave on the SIMD fills).
+            const unsigned char* sb = smem + (2 * u) * SLOT + lo16;
+            auto opnd = [&](int frag, int sub) __attribute__((always_inline)) {
+                return *reinterpret_cast<const u32x4v*>(sb + frag * 1024 + sub * 256);
+            };
+            u32x4v yv[2][2], f0[4][2], f1[4][2];
+#pragma unroll
+            for (int tx = 0; tx < 2; ++tx)
+#pragma unroll
+                for (int xi = 0; xi < 2; ++xi) yv[tx][xi] = opnd(NF + xp * 2 + tx, xi);
+#pragma unroll
+            for (int th = 0; th < 4; ++th)
+#pragma unroll
+                for (int hi = 0; hi < 2; ++hi) f0[th][hi] = opnd(hs * 4 + th, hi);
+#pragma unroll
+            for (int th = 0; th < 4; ++th)
+#pragma unroll
+                for (int hi = 0; hi < 2; ++hi) f1[th][hi] = opnd(NH + hs * 4 + th, hi);
+            auto mma16 = [&](const u32x4v (&f)[4][2]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int th = 0; th < 4; ++th)
+#pragma unroll
+                    for (int hi = 0; hi < 2; ++hi)
+#pragma unroll
+                        for (int tx = 0; tx < 2; ++tx)
+#pragma unroll
+                            for (int xi = 0; xi < 2; ++xi)
+                                acq[tx][th][hi][xi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                    __builtin_bit_cast(bf16x8, f[th][hi]), __builtin_bit_cast(bf16x8, yv[tx][xi]), acq[tx][th][hi][xi], 0, 0, 0);
+            };
+            mma16(f0);
+            dma_step(2 * (st + 2), 2 * ((u + 2) % 3));
+            // pinned order: the 12 reads of the hi part; per 2 MFMAs one read of the lo part; then one piece per 4 MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            mma16(f1);
+            dma_step(2 * (st + 2) + 1, 2 * ((u + 2) % 3) + 1);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // run-ahead pieces (slack of the tiled buffers) still target this LDS
+    if (!active) return;
+    // 16 x 16 tile (hi, xi): lane (q, c) holds column x = 16 xi + c, rows h = 16 hi + 4 q + t in register t.  The 32 x 32 tile
+    // wants lane (half, c') = column c', register r = 4 g + t <-> row (r & 3) + 8 (r >> 2) + 4 half, i.e. half = q & 1,
+    // g = 2 hi + (q >> 1).  With S0, S1 = register t of sub-tiles xi = 0, 1 as rows of 16 lanes [r0 r1 r2 r3]:
+    // v_permlane16_swap -> [S0.r0 S1.r0 S0.r2 S1.r2], [S0.r1 S1.r1 S0.r3 S1.r3]; v_permlane32_swap of those two ->
+    // [S0.r0 S1.r0 S0.r1 S1.r1] = register 4 (2 hi) + t and [S0.r2 S1.r2 S0.r3 S1.r3] = register 4 (2 hi + 1) + t.
+    float* o = Out + (long long)split * (NH * 32) * ldOut;
+    float4* o4 = reinterpret_cast<float4*>(o);
+    const int c = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            f32x16 a;
+#pragma unroll
+            for (int hi = 0; hi < 2; ++hi)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float s0 = acq[i][h][hi][0][t], s1 = acq[i][h][hi][1][t];
+                    const auto pa = __builtin_amdgcn_permlane16_swap(fbits(s0), fbits(s1), false, false);
+                    const auto pb = __builtin_amdgcn_permlane32_swap(pa[0], pa[1], false, false);
+                    a[4 * (2 * hi) + t] = bitsf(pb[0]);
+                    a[4 * (2 * hi + 1) + t] = bitsf(pb[1]);
+                }
+            if (frag_out) {                    // fragment-major product (see stream_gemm_kernel)
+                float4* t4 = o4 + (((long long)(tile0 + i) * NH + hs * 4 + h) * 64 + lane) * 4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) t4[q] = float4{a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
+            } else {
+                const long long x = (long long)(tile0 + i) * 32 + c;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[(long long)((hs * 4 + h) * 32 + rho(r, half)) * ldOut + x] = a[r];
+            }
+        }
+}
+
 }  // namespace vbmf

@@ -111,6 +111,8 @@ struct vbmf_ctx {
     int gslab_cap = 256;
     size_t gslab_bytes = 0;           // allocated size of gslab: every Gram launcher checks its slab count against it
     bool xcd_map = true;              // XCD-aware work map for split-K pass launches (env VBMF_XCD_MAP=0 turns it off)
+    bool lds8 = true;                 // H >= 128, bf16x2 operands: the 512-thread LDS-DMA streaming kernel (env VBMF_LDS8=0: the per-wave kernel,
+                                      // kept for A/B runs and for the fp32 / single-bf16 operand modes)
     bool P_frag = false;              // the Y'B product in c->P / c->Pred is fragment-major (stream_gemm.hpp, frag_out)
     bool B32_stale = false;           // the register epilogue skipped the fp32 store of B (inside vbmf_run): tiles are current
     int sready_seq = 0;               // sequence number of the Sigma-table release flag (register epilogue)
@@ -321,6 +323,8 @@ static void prof_harvest(vbmf_ctx* c) {
     c->pev.clear();
 }
 
+static bool use_lds8(const vbmf_ctx* c) { return c->lds8 && c->NH >= 4 && c->mode == MODE_BF16X2; }
+
 static size_t ctrl_lds_bytes(int NH) {
     const int R = NH <= 4 ? 2 * NH : 0;
     if (R == 0) return 0;
@@ -378,7 +382,18 @@ static int launch_stream(vbmf_ctx* c, int pass, int ctrl_mode = 0, bool epi = fa
     }
     const size_t lds = ctrl_mode ? ctrl_lds_bytes(c->NH) : 0;
     prof_begin(c, pass);
-    if (epi) {
+    if (use_lds8(c) && !epi) {
+        if (lds > (size_t)LDS8_BYTES) FAIL(c, VBMF_ERR_INVALID, "internal: control chain needs %zu bytes of LDS", lds);
+        // same workgroup footprint as the per-wave kernel (8 x tiles at H = 256, 16 at H = 128): grid, split-K plan and the
+        // XCD-aware map carry over unchanged
+        if (c->NH == 4) {
+            hipLaunchKernelGGL((stream_lds8_kernel<4, StreamCfg<4>::Rc>), dim3(grid), dim3(512), LDS8_BYTES, c->stream, Y, F, out, d.XT, d.KS,
+                               d.steps_per_split, d.nsplit, ld, c->ints + I_STOP, ca, xper, ea.frag_out);
+        } else {
+            hipLaunchKernelGGL((stream_lds8_kernel<8, 0>), dim3(grid), dim3(512), LDS8_BYTES, c->stream, Y, F, out, d.XT, d.KS,
+                               d.steps_per_split, d.nsplit, ld, c->ints + I_STOP, ca, xper, ea.frag_out);
+        }
+    } else if (epi) {
         DISPATCH_MODE(c->mode, {
             if (c->NH == 1) {
                 using Cfg = StreamCfg<1>;
@@ -905,17 +920,22 @@ static int prepare_trYBA(vbmf_ctx* c, int* flag) {
     if (c->tr_valid) return VBMF_OK;
     double* dst = c->st + c->lay.GX();
     HIPCHK(c, hipMemsetAsync(dst, 0, sizeof(double), c->stream));
+    // per-workgroup shares into c->ypart (scratch outside set_Y: <= 1024 of its 16384 doubles), folded in fixed order
     if (c->P_valid) {
         const float* In = (sharded(c) || c->d1.nsplit > 1) ? c->Pred : c->P;
         const int ns = 1;
         const long long ld = (long long)c->d1.XT * 32;
-        hipLaunchKernelGGL(dot_kernel, dim3(grid_for(c->M, 256, 1024)), dim3(256), 0, c->stream, In, ld, ns,
-                           (long long)c->Hp * ld, c->A32, c->Hp, (long long)c->M, dst, c->P_frag ? c->NH : 0);
+        const int g = grid_for(c->M, 256, 1024);
+        hipLaunchKernelGGL(dot_kernel, dim3(g), dim3(256), 0, c->stream, In, ld, ns,
+                           (long long)c->Hp * ld, c->A32, c->Hp, (long long)c->M, c->ypart, c->P_frag ? c->NH : 0);
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, c->stream, c->ypart, g, dst);
     } else {
         TRY(launch_stream(c, 1));
         const long long ld = (long long)c->d2.XT * 32;
-        hipLaunchKernelGGL(dot_kernel, dim3(grid_for(c->L, 256, 1024)), dim3(256), 0, c->stream, c->Q, ld, c->d2.nsplit,
-                           (long long)c->Hp * ld, c->B32[c->bcur], c->Hp, (long long)c->L, dst, 0);
+        const int g = grid_for(c->L, 256, 1024);
+        hipLaunchKernelGGL(dot_kernel, dim3(g), dim3(256), 0, c->stream, c->Q, ld, c->d2.nsplit,
+                           (long long)c->Hp * ld, c->B32[c->bcur], c->Hp, (long long)c->L, c->ypart, 0);
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, c->stream, c->ypart, g, dst);
         if (sharded(c)) TRY(allreduce_sum(c, dst, 1, true));
     }
     HIPCHK(c, hipGetLastError());
@@ -1056,6 +1076,7 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
     c->NH = c->Hp / 32;
     if (const char* e = getenv("VBMF_XCD_MAP")) c->xcd_map = atoi(e) != 0;      // A/B switch for the tuning record
     if (const char* e = getenv("VBMF_EPI_BALANCE")) c->epi_balance = atoi(e) != 0;
+    if (const char* e = getenv("VBMF_LDS8")) c->lds8 = atoi(e) != 0;
     // H >= 128: one Gram workgroup per chunk (gram_tiles_kernel): enough chunks to fill the chip, few enough that the
     // fp64 reduction over the chunks' dense H x H slabs stays small (it was 412 us at 1M rows with 16-tile chunks)
     c->tiles_per_chunk = c->NH >= 4 ? (int)std::max<int64_t>(16, cdiv(cdiv(std::max(L, M), 32), 384)) : 32;
@@ -1063,6 +1084,14 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
         if (c->o.factor_dtype != VBMF_FACTOR_AUTO) { c->err = "f32 Y takes f32 factor operands (factor_dtype must be AUTO)"; return bail(VBMF_ERR_INVALID); }
         c->mode = MODE_F32;
     } else if (c->o.y_dtype == VBMF_Y_BF16) {
+        // single-bf16 factor operands carry ~3 significant digits: a speed option whose stated tolerance (factors 4e-2,
+        // sigma2 only loosely) holds up to rank 128 in the GPU suite; at H = 200 on rank-8 data the residual
+        // ||Y||^2 - 2 tr + tr(..) falls below that noise and sigma2 comes out 157x off after three sweeps.  Refused above 128.
+        if (c->o.factor_dtype == VBMF_FACTOR_BF16 && H > VBMF_FACTOR_BF16_MAX_H) {
+            c->err = "factor_dtype VBMF_FACTOR_BF16 (single bf16 rounding of the factor operand) is supported up to H = 128; "
+                     "use VBMF_FACTOR_BF16X2 (hi + lo) or fp32 storage at this rank";
+            return bail(VBMF_ERR_UNSUPPORTED);
+        }
         c->mode = (c->o.factor_dtype == VBMF_FACTOR_BF16) ? MODE_BF16 : MODE_BF16X2;
     } else { c->err = "bad y_dtype"; return bail(VBMF_ERR_INVALID); }
     c->kstep = kstep_of(c->mode);
@@ -1182,6 +1211,10 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
                                         hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
             });
         }
+        if (e == hipSuccess && c->NH == 4)
+            e = hipFuncSetAttribute((const void*)stream_lds8_kernel<4, StreamCfg<4>::Rc>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8_BYTES);
+        if (e == hipSuccess && c->NH == 8)
+            e = hipFuncSetAttribute((const void*)stream_lds8_kernel<8, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8_BYTES);
         if (e != hipSuccess) { c->err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"; return bail(VBMF_ERR_HIP); }
     }
     // the zero-fills above ran on the null stream; all later work runs on a non-blocking stream
