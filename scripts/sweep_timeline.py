@@ -18,7 +18,7 @@ def short(n):
 
 
 # a sweep starts at a launch of the streaming kernel that follows a pair/gram reduce (pass 1); find pass-1 launches
-idx = [i for i, e in enumerate(ev) if "stream_gemm_kernel" in e[2]]
+idx = [i for i, e in enumerate(ev) if "stream_gemm_kernel" in e[2] or "stream_lds8_kernel" in e[2]]
 # pass 1 and pass 2 alternate in the run loop: take launches from the end
 starts = idx[::2] if len(idx) % 2 == 0 else idx[1::2]
 s0, s1 = starts[-back - 1], starts[-back]

@@ -12,6 +12,7 @@
 // 64..128-wide matrix the cost is negligible next to the streaming passes.
 #pragma once
 #include "common.hpp"
+#include "blk_inverse.hpp"
 
 namespace vbmf {
 
@@ -351,6 +352,32 @@ __device__ __forceinline__ int load_stop(const int* ints) {
     return __hip_atomic_load(ints + I_STOP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Inverse of an SPD matrix of order H <= 16 NB in LDS by the FOUR waves of a 256-thread control workgroup (blk_inverse.hpp:
+// blocked symmetric sweep, the 16 x 16 diagonal blocks inside a wavefront, rank-16 updates on the fp64 MFMA, two barriers per
+// BLOCK step where round 2's register-tiled Gauss-Jordan had a barrier and two LDS round trips per pivot).
+//   elem(i, j): the matrix (i, j < H);  W: 16 NB x (16 NB + 2) doubles of LDS;  on return W's upper triangle holds -inverse
+//   (read it through spd_inv_at), *logdet = log det of the matrix, *bad != 0 if a pivot was not positive / finite.
+// Every thread of the control workgroup (ctrl_nthreads() = 256 of them) must call it.
+template <int NB, class ElemF>
+__device__ __forceinline__ void spd_inverse_lds4(double* W, int H, ElemF elem, double* logdet, int* bad) {
+    constexpr int NP = 16 * NB, LD = NP + 2;
+    for (int t = threadIdx.x; t < NP * NP; t += 256) {
+        const int i = t / NP, j = t % NP;
+        W[i * LD + j] = (i < H && j < H) ? elem(i, j) : (i == j ? 1.0 : 0.0);      // identity padding
+    }
+    __syncthreads();
+    PivAcc pv;
+    blk_sweep<NB, 4>(W, LD, (H + 15) >> 4, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), threadIdx.x & 63, pv);
+    *logdet = pv.logdet();
+    *bad = pv.bad;
+}
+template <int NB>
+__device__ __forceinline__ double spd_inv_at(const double* W, int i, int j) {          // element (i, j) of the inverse
+    constexpr int LD = 16 * NB + 2;
+    return -(i <= j ? W[i * LD + j] : W[j * LD + i]);
+}
+constexpr size_t spd_inverse_lds_bytes(int NB) { return (size_t)(16 * NB) * (16 * NB + 2) * sizeof(double); }
+
 // which = 0: SigmaA from (GB, SigmaB, ca), N = L_global.  which = 1: SigmaB from (GA, SigmaA, cb), N = M.
 // Needs T*T threads and (4*T*R + T*R) doubles of LDS at `lds`; every thread of the block must call it.
 // shadow (which = 0, H <= 128 only): SigmaA and its log-determinant go to the W0 scratch / the shadow scalar instead
@@ -394,33 +421,25 @@ __device__ __forceinline__ void ctrl_cov_dev(double* __restrict__ st, StateLayou
             S32[(long long)i * Hp + j] = (float)v;
         }
     } else {
-        double w[R][R];
-#pragma unroll
-        for (int a = 0; a < R; ++a)
-#pragma unroll
-            for (int b = 0; b < R; ++b) {
-                const int i = ty + T * a, j = tx + T * b;
-                double v = (i == j) ? 1.0 : 0.0;                    // identity padding
-                if (i < H && j < H) {
-                    v = G[(long long)i * Hp + j] + N * Sother[(long long)i * Hp + j];
-                    if (i == j) v += sigma2 / cdiag[i];
-                }
-                w[a][b] = v;
-            }
-        double* strip = lds;
-        pivs = lds + 4 * NP;
-        gj_tiled<R, T>(w, H, strip, pivs);
-#pragma unroll
-        for (int a = 0; a < R; ++a)
-#pragma unroll
-            for (int b = 0; b < R; ++b) {
-                const int i = ty + T * a, j = tx + T * b;
-                if (i < Hp && j < Hp) {
-                    const double v = (i < H && j < H) ? w[a][b] : 0.0;
-                    Sself[(long long)i * Hp + j] = sigma2 * v;
-                    S32[(long long)i * Hp + j] = (float)v;          // Sigma/sigma2: what the post kernel multiplies by
-                }
-            }
+        // H <= 128: blocked sweep in LDS (spd_inverse_lds4)
+        static_assert(T == 16, "four waves");
+        constexpr int NBc = NP / 16;
+        double ldK; int badK;
+        spd_inverse_lds4<NBc>(lds, H, [&](int i, int j) {
+            double v = G[(long long)i * Hp + j] + N * Sother[(long long)i * Hp + j];
+            if (i == j) v += sigma2 / cdiag[i];
+            return v;
+        }, &ldK, &badK);
+        for (int t = threadIdx.x; t < Hp * Hp; t += 256) {
+            const int i = t / Hp, j = t % Hp;
+            const double v = (i < H && j < H) ? spd_inv_at<NBc>(lds, i, j) : 0.0;
+            Sself[(long long)i * Hp + j] = sigma2 * v;
+            S32[(long long)i * Hp + j] = (float)v;                  // Sigma/sigma2: what the post kernel multiplies by
+        }
+        if (badK) atomicExch(ints + I_ERR, 1);
+        if (threadIdx.x == 0)
+            scal[which == 0 ? (shadow ? S_LOGDET_SA_SHADOW : S_LOGDET_SA) : S_LOGDET_SB] = (double)H * log(sigma2) - ldK;
+        return;
     }
     __syncthreads();
     double ld = 0.0;

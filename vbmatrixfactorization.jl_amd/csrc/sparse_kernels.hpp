@@ -178,6 +178,113 @@ __global__ __launch_bounds__(T * T) void sparse_update_a_full_kernel(const float
             if (i < Hp && j < Hp) part[(long long)blockIdx.x * Hp * Hp + (long long)i * Hp + j] = acc[a][b];
         }
 }
+// Round 3, H <= 64: ONE COLUMN OF Y PER WAVEFRONT -- the column's H x H block staged in the wave's own LDS image and inverted
+// there by the blocked symmetric sweep of blk_inverse.hpp (16 x 16 diagonal blocks swept inside the wave, rank-16 updates on
+// the fp64 MFMA): no s_barrier anywhere in the loop over the columns, NW independent waves per workgroup.  What north_star
+// describes ("the small H x H covariance staged and inverted in LDS per wavefront").  The part of K_m that does not depend on
+// m, k0 = gsc G + sigma L SigmaB, stays in registers as the upper blocks in the MFMA's C/D layout and is written into the
+// image with the column's diag(CA[m,:]) added on the way; so does the running sum of the Sigma_m.
+//   NBK: 16-blocks per side (H <= 16 NBK); NW: waves per workgroup (NW images of 16 NBK x (16 NBK + 2) doubles of LDS).
+template <int NBK, int NW>
+__global__ __launch_bounds__(NW * 64) void sparse_update_a_full_wave_kernel(const float* __restrict__ P, long long ldP,
+                                                                            const float* __restrict__ CA32,
+                                                                            const double* __restrict__ st, StateLayout lay,
+                                                                            float* __restrict__ A32, float* __restrict__ dS32,
+                                                                            const unsigned char* __restrict__ mask, int hmask_start,
+                                                                            long long M, int H, int Hp, double Lg,
+                                                                            double* __restrict__ part, int* __restrict__ ints,
+                                                                            const double* __restrict__ Gw = nullptr) {
+    extern __shared__ __attribute__((aligned(16))) double lds_fw[];
+    if (load_stop(ints)) return;
+    constexpr int NP = 16 * NBK, LD = NP + 2, NUP = NBK * (NBK + 1) / 2;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c16 = lane & 15, q16 = lane >> 4;
+    double* W = lds_fw + (size_t)w * NP * LD;
+    double* pvec = lds_fw + (size_t)NW * NP * LD + w * NP;          // (B'Y)[:, m] of this wave's column
+    const int nbu = (H + 15) >> 4;
+    // (see sparse_update_a_full_kernel for the heteroscedastic form: Gw, gsc, msc)
+    const double sig = st[lay.scal() + S_SIGMA2];
+    const double gsc = Gw != nullptr ? 1.0 : sig, msc = Gw != nullptr ? 1.0 : sig;
+    const double* G = Gw != nullptr ? Gw : st + lay.GB();
+    f64x4 k0[NUP], acc[NUP];
+    {
+        int u = 0;
+#pragma unroll
+        for (int I = 0; I < NBK; ++I)
+#pragma unroll
+            for (int J = I; J < NBK; ++J, ++u) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * I + q16 + 4 * r, j = 16 * J + c16;
+                    k0[u][r] = (i < H && j < H) ? gsc * G[(long long)i * lay.Hp + j] + sig * Lg * st[lay.SB() + (long long)i * lay.Hp + j]
+                                                : (i == j ? 1.0 : 0.0);                       // identity padding
+                    acc[u][r] = 0.0;
+                }
+            }
+    }
+    int bad = 0;
+    for (long long m = (long long)blockIdx.x * NW + w; m < M; m += (long long)gridDim.x * NW) {
+        {   // K_m = k0 + diag(CA[m,:]) into the image (upper blocks; the diagonal element of row 16 I + c sits in lane row c & 3, register c >> 2)
+            int u = 0;
+#pragma unroll
+            for (int I = 0; I < NBK; ++I)
+#pragma unroll
+                for (int J = I; J < NBK; ++J, ++u) {
+                    f64x4 x = k0[u];
+                    if (I == J) {
+                        const int i = 16 * I + c16;
+                        const double ca = i < H ? (double)CA32[m * Hp + i] : 0.0;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) x[r] += (q16 == (c16 & 3) && r == (c16 >> 2)) ? ca : 0.0;
+                    }
+                    if (I < nbu && J < nbu) blk_st_rows(W, LD, I, J, lane, x);
+                }
+        }
+        for (int h = lane; h < NP; h += 64) pvec[h] = h < H ? (double)P[(long long)h * ldP + m] : 0.0;
+        PivAcc pv;
+        blk_sweep<NBK, 1>(W, LD, nbu, 0, lane, pv);                     // W's upper blocks = -Sigma_m
+        bad |= pv.bad;
+        // vec(A')[m,:] = msc Sigma_m (B'Y)[:, m]: lane i takes row i of the symmetric matrix (upper storage)
+        for (int i = lane; i < H; i += 64) {
+            double sm = 0.0;
+            for (int j = 0; j < i; ++j) sm += W[j * LD + i] * pvec[j];
+            for (int j = i; j < H; ++j) sm += W[i * LD + j] * pvec[j];
+            float av = (float)(-msc * sm);
+            if (mask != nullptr && i >= hmask_start && mask[m]) av = 0.f;
+            A32[m * Hp + i] = av;
+            dS32[m * Hp + i] = (float)(-W[i * LD + i]);
+        }
+        {
+            int u = 0;
+#pragma unroll
+            for (int I = 0; I < NBK; ++I)
+#pragma unroll
+                for (int J = I; J < NBK; ++J, ++u)
+                    if (I < nbu && J < nbu) acc[u] -= blk_ld_rows(W, LD, I, J, lane);
+        }
+    }
+    if (bad) atomicExch(ints + I_ERR, 1);
+    // fold the NW waves' sums through their images (fixed order), one dense Hp x Hp partial per workgroup
+    {
+        int u = 0;
+#pragma unroll
+        for (int I = 0; I < NBK; ++I)
+#pragma unroll
+            for (int J = I; J < NBK; ++J, ++u) blk_st_rows(W, LD, I, J, lane, acc[u]);
+    }
+    __syncthreads();
+    double* mypart = part + (long long)blockIdx.x * Hp * Hp;
+    for (int t = threadIdx.x; t < Hp * Hp; t += NW * 64) {
+        const int i = t / Hp, j = t % Hp;
+        double sm = 0.0;
+        if (i < H && j < H) {
+            const int a = i <= j ? i : j, b = i <= j ? j : i;
+            for (int ww = 0; ww < NW; ++ww) sm += lds_fw[(size_t)ww * NP * LD + a * LD + b];
+        }
+        mypart[t] = sm;
+    }
+}
+
 // 128 < H <= 256 (Hp = 256): a 256 x 256 fp64 block is the whole register file of a CU, so the column's block goes through the
 // blocked Schur inverse of the control chain (inv256_schur, ctrl_kernels.hpp: two 128 x 128 register-tiled inverses + four
 // LDS-panelled fp64 GEMMs) with the matrices in a per-workgroup GLOBAL workspace ws[b] = [K | inv(K) | W | S] (1.25 MiB, L2).
@@ -474,33 +581,24 @@ __global__ __launch_bounds__(T * T) void sparse_cov_b_kernel(double* __restrict_
             S32[(long long)i * Hp + j] = (float)(s32_unit ? v : sig * v);
         }
     } else {
-        double w[R][R];
-#pragma unroll
-        for (int a = 0; a < R; ++a)
-#pragma unroll
-            for (int b = 0; b < R; ++b) {
-                const int i = ty + T * a, j = tx + T * b;
-                double v = (i == j) ? 1.0 : 0.0;
-                if (i < H && j < H) {
-                    v = sig * (st[lay.GA() + (long long)i * Hp + j] + st[lay.SA() + (long long)i * Hp + j]);
-                    if (i == j) v += cb[i];
-                }
-                w[a][b] = v;
-            }
-        double* strip = lds_scb;
-        pivs = lds_scb + 4 * NP;
-        gj_tiled<R, T>(w, H, strip, pivs);
-#pragma unroll
-        for (int a = 0; a < R; ++a)
-#pragma unroll
-            for (int b = 0; b < R; ++b) {
-                const int i = ty + T * a, j = tx + T * b;
-                if (i < Hp && j < Hp) {
-                    const double v = (i < H && j < H) ? w[a][b] : 0.0;
-                    st[lay.SB() + (long long)i * Hp + j] = v;
-                    S32[(long long)i * Hp + j] = (float)(s32_unit ? v : sig * v);
-                }
-            }
+        // H <= 128: blocked sweep in LDS (ctrl_kernels.hpp, spd_inverse_lds4)
+        static_assert(T == 16, "four waves");
+        constexpr int NBc = NP / 16;
+        double ldK; int badK;
+        spd_inverse_lds4<NBc>(lds_scb, H, [&](int i, int j) {
+            double v = sig * (st[lay.GA() + (long long)i * Hp + j] + st[lay.SA() + (long long)i * Hp + j]);
+            if (i == j) v += cb[i];
+            return v;
+        }, &ldK, &badK);
+        for (int t = threadIdx.x; t < Hp * Hp; t += 256) {
+            const int i = t / Hp, j = t % Hp;
+            const double v = (i < H && j < H) ? spd_inv_at<NBc>(lds_scb, i, j) : 0.0;
+            st[lay.SB() + (long long)i * Hp + j] = v;
+            S32[(long long)i * Hp + j] = (float)(s32_unit ? v : sig * v);
+        }
+        if (badK) atomicExch(ints + I_ERR, 1);
+        if (threadIdx.x == 0) scal[S_LOGDET_SB] = -ldK;     // log det SigmaB
+        return;
     }
     __syncthreads();
     double ld = 0.0;

@@ -329,7 +329,8 @@ static size_t ctrl_lds_bytes(int NH) {
     const int R = NH <= 4 ? 2 * NH : 0;
     if (R == 0) return 0;
     const size_t NP = 16 * (size_t)R;
-    return std::max((size_t)2 * NP * (NP + 4) * sizeof(float), (size_t)5 * 16 * R * sizeof(double));
+    // lambda_max (two NP x (NP + 4) fp32 images) | the blocked inverse's NP x (NP + 2) fp64 image (ctrl_kernels.hpp)
+    return std::max((size_t)2 * NP * (NP + 4) * sizeof(float), spd_inverse_lds_bytes(R));
 }
 static bool fused_ctrl(const vbmf_ctx* c) { return c->in_run && c->NH <= 4; }
 
@@ -703,7 +704,7 @@ static bool side_overlap(const vbmf_ctx* c) { return c->in_run && c->NH == 8; }
 
 template <int R, int T>
 static void launch_cov_t(vbmf_ctx* c, int which, hipStream_t s) {
-    const size_t lds = (R == 8 && T == 32) ? (size_t)(2 * 16 * GEMM_LD + 512 + 256) * sizeof(double) : (size_t)(5 * T * R) * sizeof(double);
+    const size_t lds = (R == 8 && T == 32) ? (size_t)(2 * 16 * GEMM_LD + 512 + 256) * sizeof(double) : spd_inverse_lds_bytes(R);
     const double N = which == 0 ? (double)c->Lg : (double)c->M;
     hipLaunchKernelGGL((ctrl_cov_kernel<R, T>), dim3(1), dim3(T * T), lds, s, c->st, c->lay, (int)c->H, which, N,
                        which == 0 ? c->SA32 : c->SB32, c->ints);
@@ -1204,6 +1205,9 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
     c->lds_limit = 160 * 1024 - 16384;         // leaves room for the kernels' static LDS (ctrl_end's tables: 8.4 KB)
     {
         hipError_t e = hipFuncSetAttribute((const void*)eig_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
+        // 64 < H <= 128: the blocked inverse keeps the 128 x 130 fp64 image in LDS (133 KB)
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ctrl_cov_kernel<8, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)sparse_cov_b_kernel<8, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
         if (e == hipSuccess && c->NH == 4) {
             using Cfg = StreamCfg<4>;
             DISPATCH_MODE(c->mode, {
@@ -1892,7 +1896,7 @@ static double digamma_host(double x) {
 
 template <int R, int T>
 static void launch_scov_t(vbmf_ctx* c) {
-    const size_t lds = (R == 8 && T == 32) ? (size_t)(2 * 16 * GEMM_LD + 512 + 256) * sizeof(double) : (size_t)(5 * T * R) * sizeof(double);
+    const size_t lds = (R == 8 && T == 32) ? (size_t)(2 * 16 * GEMM_LD + 512 + 256) * sizeof(double) : spd_inverse_lds_bytes(R);
     hipLaunchKernelGGL((sparse_cov_b_kernel<R, T>), dim3(1), dim3(T * T), lds, ctrl_stream(c), c->st, c->lay, (int)c->H, c->SB32, c->ints, c->diagvar ? 1 : 0);
 }
 static int launch_sparse_cov_b(vbmf_ctx* c) {
@@ -1921,6 +1925,23 @@ static void launch_full_a_t(vbmf_ctx* c, const double* Gw = nullptr) {
     hipLaunchKernelGGL((sparse_update_a_full_kernel<R, T, NB>), dim3(c->fblocks), dim3(T * T), (size_t)(6 * NB * T * R) * sizeof(double), c->stream,
                        c->Pred, (long long)c->d1.XT * 32, c->CA32, c->st, c->lay, c->A32, c->dS32, c->has_mask ? c->mask : nullptr,
                        (int)(c->H - c->H1), (long long)c->M, (int)c->H, c->Hp, (double)c->Lg, c->fpart, c->ints, Gw);
+}
+
+// H <= 64: one column of Y per wavefront (sparse_kernels.hpp, sparse_update_a_full_wave_kernel); returns the number of partial
+// sums of Sigma_m it leaves in c->fpart (one per workgroup)
+template <int NBK, int NW>
+static int launch_full_a_wave(vbmf_ctx* c, const double* Gw) {
+    constexpr size_t lds = ((size_t)NW * 16 * NBK * (16 * NBK + 2) + (size_t)NW * 16 * NBK) * sizeof(double);
+    static bool attr_set = false;                              // (per instantiation; the attribute is per device function)
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)sparse_update_a_full_wave_kernel<NBK, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(c->fblocks, cdiv(c->M, NW)), 2 * (NUM_CU + 2)));
+    hipLaunchKernelGGL((sparse_update_a_full_wave_kernel<NBK, NW>), dim3(grid), dim3(NW * 64), lds, c->stream,
+                       c->Pred, (long long)c->d1.XT * 32, c->CA32, c->st, c->lay, c->A32, c->dS32, c->has_mask ? c->mask : nullptr,
+                       (int)(c->H - c->H1), (long long)c->M, (int)c->H, c->Hp, (double)c->Lg, c->fpart, c->ints, Gw);
+    return grid;
 }
 
 // B' diag(sigmaVecHat) B summed over the row shards (full_cov with diag_var, src/vbmf_sparse.jl:180-182): the plain Gram (exact-f32
@@ -1984,15 +2005,16 @@ static int do_sparse_update_A(vbmf_ctx* c, bool reuse_P = false) {
         const int H = (int)c->H;
         const double* Gw = nullptr;
         if (c->diagvar) TRY(weighted_gram_B(c, &Gw));
-        if (H <= 16) launch_full_a_t<1, 16>(c, Gw);
-        else if (H <= 32) launch_full_a_t<2, 16>(c, Gw);
-        else if (H <= 64) launch_full_a_t<4, 16>(c, Gw);
+        int nparts = c->fblocks;
+        if (H <= 16) nparts = launch_full_a_wave<1, 8>(c, Gw);  // H <= 64: one column per wavefront, blocked sweep in the wave's LDS image
+        else if (H <= 32) nparts = launch_full_a_wave<2, 8>(c, Gw);
+        else if (H <= 64) nparts = launch_full_a_wave<4, 4>(c, Gw);
         else if (H <= 128) launch_full_a_t<8, 16, 1>(c, Gw);   // 64 < H <= 128: one column per round and workgroup
         else                                               // 128 < H <= 256: blocked Schur inverse through a global workspace
             hipLaunchKernelGGL(sparse_update_a_full256_kernel, dim3(c->fblocks), dim3(1024), (size_t)(2 * 16 * GEMM_LD + 512 + 256 + 256) * sizeof(double),
                                c->stream, c->Pred, (long long)c->d1.XT * 32, c->CA32, c->st, c->lay, c->A32, c->dS32,
                                c->has_mask ? c->mask : nullptr, (int)(c->H - c->H1), (long long)c->M, H, (double)c->Lg, c->fpart, c->ints, Gw, c->fws);
-        hipLaunchKernelGGL(full_sa_fold_kernel, dim3(cdiv(c->Hp * c->Hp, 256)), dim3(256), 0, c->stream, c->fpart, c->fblocks, c->Hp, c->st, c->lay, stop);
+        hipLaunchKernelGGL(full_sa_fold_kernel, dim3(cdiv(c->Hp * c->Hp, 256)), dim3(256), 0, c->stream, c->fpart, nparts, c->Hp, c->st, c->lay, stop);
         HIPCHK(c, hipGetLastError());
         TRY(launch_retile(c, 0, true));
         TRY(launch_gram(c, 0, c->A32, nullptr, true));
