@@ -129,7 +129,13 @@ int vbmf_run_fixed_basis(vbmf_ctx* ctx, int64_t niter);
 /* The vbmf! loop (src/vbmf.jl:187-214): while i <= niter && d > eps { A; B; [CA; CB]; [sigma2]; d }.
  * Runs entirely on the device; the stop test is evaluated device-side so the state freezes exactly
  * where the reference would stop.  iters_done = i-1 (src/vbmf.jl:221), d_last = last d.
- * trace (optional, niter x 4 doubles, row-major): per sweep d, sigma2, elbo, reserved. */
+ * trace (optional, niter x 4 doubles, row-major): per sweep d, sigma2, elbo, reserved.
+ * eps: the reference's default 1e-6 (src/vbmf.jl:175) is at or below what d resolves on the device (BHat is stored in fp32 /
+ * as bf16 hi + lo: d floors at ~1e-6 / ~1e-5 where the fp64 reference keeps falling).  A run that uses all niter sweeps with d
+ * still above such an eps returns VBMF_OK and leaves a text starting with "note:" in vbmf_last_error (cleared by the next run);
+ * the Python / Julia hosts turn it into a warning.
+ * Row-sharded runs: a device error on one rank (VBMF_ERR_NUMERIC / VBMF_ERR_SYNC) stops every rank at the same sweep and every
+ * rank returns that error class -- the ranks' error flags travel with the packed Gram all-reduce. */
 int vbmf_run(vbmf_ctx* ctx, int64_t niter, double eps, int est_covs, int est_var, int64_t* iters_done,
              double* d_last, double* trace);
 
@@ -285,6 +291,8 @@ int vbmf_debug_time_pass(vbmf_ctx* ctx, int pass, int iters, double* ms);
 /* test hooks for the in-launch hand-off of the Y*A pass's register epilogue (VBMF_ERR_SYNC path) */
 #define VBMF_DEBUG_EPI_SPIN_LIMIT 0   /* polls (~0.4 us each) the epilogue waits for the SigmaB table before giving up; default 2^22 */
 #define VBMF_DEBUG_EPI_EXPECT_SKEW 1  /* != 0: the epilogue waits for a sequence number nobody publishes (forces the timeout) */
+#define VBMF_DEBUG_SIGMA_B_PPM 2      /* test hook: the SigmaB / sigma2 table the B update multiplies by is scaled by (1 + value * 1e-6) --
+                                         a deliberate, known-size regression that the parity asserts must catch (tests/test_gpu_soak.py) */
 int vbmf_debug_set(vbmf_ctx* ctx, int what, int64_t value);
 
 #ifdef __cplusplus

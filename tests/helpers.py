@@ -1,5 +1,6 @@
 """Shared helpers for the GPU parity tests (oracle = checker only)."""
 import os
+import sys
 
 import numpy as np
 
@@ -8,10 +9,40 @@ from oracle import vbmf_oracle as O
 REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_report.txt")
 
 
+BASELINE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gpu_parity_baseline.json")
+# a measured error may move by rounding luck when a kernel's summation order changes; below this it is fp32 storage noise
+BASELINE_FLOOR = 3e-6
+BASELINE_FACTOR = 3.0
+_baseline = None
+
+
+def baseline_guard(line):
+    """Regression guard under every comparison: `line` is a report line `<tag>: field=err ...`; each error must stay within
+    max(3 x the figure measured on an MI355X for that tag and field, BASELINE_FLOOR) (tests/golden/make_parity_baseline.py)."""
+    global _baseline
+    if _baseline is None:
+        import json
+        _baseline = json.load(open(BASELINE)) if os.path.exists(BASELINE) else {}
+    sys.path.insert(0, os.path.dirname(BASELINE))
+    try:
+        from make_parity_baseline import parse
+    finally:
+        sys.path.pop(0)
+    p = parse(line)
+    if p is None or p[0] not in _baseline:
+        return
+    tag, errs = p
+    bad = {k: (v, _baseline[tag][k]) for k, v in errs.items()
+           if k in _baseline[tag] and not v <= max(BASELINE_FACTOR * _baseline[tag][k], BASELINE_FLOOR)}
+    assert not bad, (f"regression against the measured baseline of '{tag}' (field: (now, measured)); if the change is intended, "
+                     f"regenerate tests/golden/gpu_parity_baseline.json", bad)
+
+
 def report(line):
     os.makedirs(os.path.dirname(REPORT), exist_ok=True)
     with open(REPORT, "a") as f:
         f.write(line + "\n")
+    baseline_guard(line)
 
 
 def relF(a, b):

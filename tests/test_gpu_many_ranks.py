@@ -128,3 +128,51 @@ def test_many_ranks_one_gpu_threads(pkg, world, L, M, H, niter):
     report(f"{world} ranks (threads, one GPU) vs fp64 ORACLE, {L}x{M} H={H}, {niter} sweeps: " + " ".join(f"{k}={v:.2e}" for k, v in e2.items()))
     assert max(e2[k] for k in ("A", "B", "SA", "SB", "ca", "cb")) < 2e-4, e2          # bf16x2 path: 1e-4 per update
     assert e2["s2"] < 1e-3 and e2["d"] < 2e-2 and e2["elbo"] < 1e-4, e2
+
+
+def test_error_on_one_rank_stops_every_rank(pkg):
+    """A device error on ONE rank of a row-sharded run must stop EVERY rank, at the same sweep, with the same error class:
+    the ranks' error flags travel as one more number of the packed Gram message ([B'B | dB'dB | tr(B'YA) | flag], summed by the
+    same all-reduce) and every rank's loop test reads the sum.  Rank 1's Y*A pass is made to give up its in-launch hand-off
+    (VBMF_DEBUG_EPI_EXPECT_SKEW with a short spin limit); before round 3 rank 0 ran on into the all-reduces with rank 1's
+    garbage partials and returned OK."""
+    world, n, M, H, niter = 2, 70000, 1100, 48, 6               # per-rank shard = the shape of test_epilogue_handoff_timeout_is_reported
+    L = world * n
+    rng = np.random.default_rng(77)
+    A0, B0 = rng.standard_normal((M, H)), rng.standard_normal((L, H))
+    z = np.zeros((H, H))
+    ar = ThreadAllReduce(world)
+    out, errs_t = [None] * world, []
+
+    def rank_main(r):
+        try:
+            with pkg.capi.Context(n, M, H, y_dtype=pkg.VBMF_Y_BF16, nranks=world, rank=r, L_global=L, row_offset=r * n) as c:
+                dims = c.dims()
+                c.comm_set_transport(pkg.dist.host_staged_transport(ar.make(r)))
+                c.set_Y_synthetic(11, H, 0.05)
+                c.set_state(A0, B0[r * n:(r + 1) * n], z, z, 0.1 * np.ones(H), 0.1 * np.ones(H), 0.1)
+                if r == 1:
+                    c.debug_set(pkg.capi.DEBUG_EPI_SPIN_LIMIT, 2000)
+                    c.debug_set(pkg.capi.DEBUG_EPI_EXPECT_SKEW, 1)
+                try:
+                    c.run(niter, eps=0.0, est_covs=True, est_var=True)
+                    out[r] = ("ok", None, dims)
+                except pkg.VbmfError as e:
+                    out[r] = ("err", e, dims)
+        except Exception as e:                                 # a failed rank must not leave the other at the barrier
+            errs_t.append((r, repr(e)))
+            ar.bar.abort()
+
+    ths = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=300)
+    assert not errs_t, errs_t
+    dims = out[0][2]
+    if dims["nsplit2"] != 1 or dims["NH"] > 2 or dims["narrow"]:
+        pytest.skip(f"planner did not choose the un-split pass (register epilogue) here: {dims}")
+    assert out[0][0] == "err" and out[1][0] == "err", out       # BOTH ranks report the failure
+    for r in range(world):
+        assert out[r][1].code == pkg.capi.VBMF_ERR_SYNC, out[r][1]
+    assert "another rank" in str(out[0][1]) and "another rank" not in str(out[1][1]), (str(out[0][1]), str(out[1][1]))

@@ -129,6 +129,8 @@ def test_run_three_sweeps(pkg, mode, L, M, H):
     # three sweeps accumulate the per-update error of the factors and covariances (measured worst case: BHat 8.2e-5 on the f32
     # path at 1200 x 900, H = 128, against 5e-5 per update); sigma2 keeps its stated per-dtype tolerance UNMULTIPLIED: tr(Y'BA')
     # is summed directly where BHat is produced (no Gram identity on a rounded BHat any more)
+    # (measured worst case, profiles/r03 parity report: f32 BHat 7.2e-5 at H = 200, bf16x2 BHat 8.0e-5 at H = 128 -> 1e-4 / 2e-4;
+    #  every field is also held to 3x its own measured figure by helpers.baseline_guard)
     tol3 = {k: (v if k == "sigma2" else 2 * v) for k, v in tol.items()}
     if mode == "bf16":
         # single-bf16 factors: ~3 significant digits in A/B; the noise variance (a cancellation of
@@ -166,15 +168,17 @@ def test_run_trajectory_well_conditioned(pkg, mode, L, M, H):
            f"max rel dev where d>1e-4: {np.max(dd[otr[:, 0] > 1e-4] / otr[otr[:, 0] > 1e-4, 0]):.2e}; "
            f"elbo max rel dev {np.max(np.abs(tr[:, 2] - otr[:, 2]) / np.abs(otr[:, 2])):.2e}")
     assert it == 25
-    assert max(errs[k] for k in ("A", "B", "ca", "cb")) < 20 * tol["default"], errs
+    # measured (25 sweeps): A, B, ca, cb <= 1.7e-6 (f32) / 1.2e-5 (bf16x2); SA, SB, s2 <= 5.2e-5 / 3.7e-5
+    assert max(errs[k] for k in ("A", "B", "ca", "cb")) < (6e-6 if mode == "f32" else 4e-5), errs
     # Sigma = sigma2*inv(.) inherits sigma2's cancellation error
-    assert max(errs[k] for k in ("SA", "SB", "s2")) < 20 * tol["sigma2"], errs
+    assert max(errs[k] for k in ("SA", "SB", "s2")) < 1.6e-4, errs
     # bf16x2: BHat is stored as bf16 hi + lo, a grid of 2^-17 relative per entry, so near convergence d is the norm of a few
     # one-step flips on that grid: 7.6e-6 / sqrt(L*H) per flipped entry (1e-6 .. 3e-6 on the 10 x 2 factor) where the
     # oracle's d keeps falling -- the floor DESIGN.md section 2 states for `eps`
-    assert np.allclose(tr[:, 0], otr[:, 0], rtol=5e-3 if mode == "f32" else 3e-2, atol=D_ATOL if mode == "f32" else 1e-5)
-    assert np.allclose(tr[:, 1], otr[:, 1], rtol=20 * tol["sigma2"])
-    assert np.allclose(tr[:, 2], otr[:, 2], rtol=1e-3, atol=1.0)
+    # measured: d trace rel. dev (d > 1e-4) <= 5e-4 (f32) / 2.5e-3 (bf16x2), abs dev <= 6e-7 / 1.1e-5; ELBO trace rel. dev <= 1.3e-4
+    assert np.allclose(tr[:, 0], otr[:, 0], rtol=1.5e-3 if mode == "f32" else 8e-3, atol=D_ATOL if mode == "f32" else 1e-5)
+    assert np.allclose(tr[:, 1], otr[:, 1], rtol=1.6e-4)
+    assert np.allclose(tr[:, 2], otr[:, 2], rtol=4e-4, atol=1.0)
 
 
 def test_golden_fixture_trajectory(pkg, golden_dir):
@@ -201,6 +205,61 @@ def test_golden_fixture_trajectory(pkg, golden_dir):
     # Y here is fp64 -> fp32 on upload: not bit-identical inputs, hence the 2e-3 bound after 100 sweeps
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16x2"])
+def test_reference_default_eps(pkg, golden_dir, mode):
+    """The reference's DEFAULT stopping threshold, eps = 1e-6 (src/vbmf.jl:175), against the oracle's stopping sweep.
+    d = ||B_old - B||_2 / ||B_old||_2 is computed from factors stored in fp32 (bf16x2: as bf16 hi + lo), so on the device it
+    floors at ~1e-6 / ~1e-5 where the fp64 reference keeps falling.  Either the device stops within one sweep of the oracle,
+    or -- where its floor makes eps unreachable -- it uses all its sweeps and SAYS SO: vbmf_run leaves a note, the host turns it
+    into a RuntimeWarning.  (Round 2 ran silently to niter.)"""
+    import warnings
+    ydt, fdt, tol = _mode_opts(pkg, mode)
+    pkg.set_defaults(y_dtype=ydt, factor_dtype=fdt)
+    try:
+        _default_eps_body(pkg, golden_dir, mode, ydt, fdt, tol, warnings)
+    finally:
+        pkg.set_defaults(y_dtype=pkg.VBMF_Y_F32, factor_dtype=pkg.VBMF_FACTOR_AUTO)     # (the tests below set only what they change)
+
+
+def _default_eps_body(pkg, golden_dir, mode, ydt, fdt, tol, warnings):
+    # (1) the reference's recorded 10 x 20 problem: d never reaches 1e-6 in its 100 sweeps (spectral d_100 = 3.1e-6, SURVEY App. B)
+    g = np.load(os.path.join(golden_dir, "vbmf_test.npz"))
+    Ys = _stored(pkg, g["Y"], 2, ydt, fdt)
+    po = O.vbmf_parameters()
+    po.L, po.M, po.H, po.H1 = 10, 20, 2, 0
+    po.labels = np.zeros(0, dtype=np.int64)
+    for f in ("AHat", "BHat", "SigmaA", "SigmaB", "CA", "CB", "invCA", "invCB"):
+        setattr(po, f, g[f][0].copy())
+    po.sigma2 = float(g["sigma2"][0])
+    pg = to_pkg_params(pkg, po)
+    _, n, d = O.vbmf_(Ys, po, 100, eps=1e-6, est_covs=True, est_var=True)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        pkg.vbmf_(Ys, pg, 100, eps=1e-6, est_covs=True, est_var=True)
+    noted = [x for x in w if issubclass(x.category, RuntimeWarning) and "below what d resolves" in str(x.message)]
+    report(f"default eps, recorded 10x20 {mode}: oracle n={n} d={d:.3e}; gpu n={pg._last_run[0]} d={pg._last_run[1]:.3e}; note={bool(noted)}")
+    assert n == 100                                              # the reference itself ran all 100 sweeps
+    assert pg._last_run[0] == 100 or abs(pg._last_run[0] - n) <= 1
+    if pg._last_run[0] == 100 and pg._last_run[1] > 1e-6:
+        assert noted, "all sweeps used with d > eps below the device's resolution, and no note"
+    # (2) 200 x 100, rank 5 (config 1's shape): the oracle stops; the device stops with it or reports why it cannot
+    Y, po = _problem(200, 100, 5, 4242, separated=True)
+    Ys = _stored(pkg, Y, 5, ydt, fdt)
+    pg = to_pkg_params(pkg, po)
+    _, n, d = O.vbmf_(Ys, po, 300, eps=1e-6, est_covs=True, est_var=True)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        pkg.vbmf_(Ys, pg, 300, eps=1e-6, est_covs=True, est_var=True)
+    noted = [x for x in w if issubclass(x.category, RuntimeWarning) and "below what d resolves" in str(x.message)]
+    report(f"default eps, 200x100 H5 {mode}: oracle n={n} d={d:.3e}; gpu n={pg._last_run[0]} d={pg._last_run[1]:.3e}; note={bool(noted)}")
+    assert 3 < n <= 300
+    if pg._last_run[0] == 300 and n < 299:
+        assert noted and pg._last_run[1] > 1e-6, (pg._last_run, n)
+    else:
+        assert abs(pg._last_run[0] - n) <= 2, (pg._last_run, n, d)
+        compare(f"default eps run-to-stop 200x100 H5 {mode}", pg, po, dict(default=20 * tol["default"], sigma2=20 * tol["sigma2"]))
+
+
 def test_label_mask(pkg):
     """AHat[labels, end-H1+1:end] = 0 after every A update (src/vbmf.jl:101)."""
     Y, po = _problem(120, 90, 6, 41, H1=2, labels=[0, 5, 17, 89])
@@ -210,7 +269,7 @@ def test_label_mask(pkg):
     pkg.vbmf_(Yf, pg, 6, eps=0.0, est_covs=True, est_var=True)
     O.vbmf_(Yf, po, 6, eps=0.0, est_covs=True, est_var=True)
     assert np.all(pg.AHat[[0, 5, 17, 89], 4:] == 0.0) and np.all(pg.AHat[[0, 5, 17, 89], :4] != 0.0)
-    compare("mask run6", pg, po, {k: 5 * v for k, v in TOL_F32.items()})
+    compare("mask run6", pg, po, dict(default=4e-6, sigma2=3e-6))        # measured: SigmaB 1.2e-6 worst field, sigma2 3.8e-7
 
 
 def test_termination_matches_oracle(pkg):
@@ -226,7 +285,7 @@ def test_termination_matches_oracle(pkg):
     # d crosses eps steeply relative to fp32 noise only if the trajectory is not flat there: allow +-1
     assert abs(pg._last_run[0] - n) <= 1, (pg._last_run, n, d)
     assert pg._last_run[1] <= 1e-4
-    compare("termination", pg, po, {k: 50 * v for k, v in TOL_F32.items()})
+    compare("termination", pg, po, dict(default=3e-5, sigma2=6e-5))      # measured: SigmaA 9.6e-6 worst field, sigma2 1.8e-5
     # niter = 0: nothing happens (src/vbmf.jl:193)
     pg2 = to_pkg_params(pkg, po)
     pkg.vbmf_(Yf, pg2, 0)
@@ -357,7 +416,7 @@ def test_rank_above_128_slow_path(pkg):
     pg = to_pkg_params(pkg, po)
     pkg.vbmf_(Ys, pg, 2, eps=0.0, est_covs=True, est_var=True)
     _, n, d = O.vbmf_(Ys, po, 2, eps=0.0, est_covs=True, est_var=True)
-    compare("bf16x2 900x640 H200 run2", pg, po, {k: 6 * v for k, v in tol.items()})
+    compare("bf16x2 900x640 H200 run2", pg, po, dict(default=8e-5, sigma2=3e-6))   # measured: BHat 2.5e-5 worst field, sigma2 2.5e-7
     assert abs(pg._last_run[1] - d) <= 2e-2 * d
 
 
@@ -417,15 +476,18 @@ def test_rank_above_128_loop_and_termination(pkg):
     tr = []
     O.vbmf_(Ys, probe, 16, eps=0.0, est_covs=True, est_var=True, trace=tr)
     ds = np.array([t[0] for t in tr])
-    k = 5 + int(np.argmax(ds[5:12] / ds[6:13]))              # widest ratio between consecutive sweeps 6..13
+    # round 2 placed eps in the WIDEST gap of the oracle's d sequence, because lambda_max for H > 128 was a fixed-count power
+    # iteration good to ~1e-3; it now iterates to a tolerance (ctrl_kernels.hpp, EIG_POWER_TOL), so eps sits between two
+    # consecutive sweeps at a fixed place (geometric mean of d_8 and d_9), whatever the gap there
+    k = 8
     eps = float(np.sqrt(ds[k] * ds[k + 1]))
-    assert ds[k] > 1.05 * eps > 1.05 * 1.05 * ds[k + 1] or ds[k] / ds[k + 1] > 1.1
+    assert ds[k] > eps > ds[k + 1]
     pg = to_pkg_params(pkg, po)
     pkg.vbmf_(Ys, pg, 40, eps=eps, est_covs=True, est_var=True)
     _, n, d = O.vbmf_(Ys, po, 40, eps=eps, est_covs=True, est_var=True)
     report(f"H=130 termination (eps={eps:.3e}): oracle n={n} d={d:.3e}; gpu n={pg._last_run[0]} d={pg._last_run[1]:.3e}")
     assert n == k + 2 and pg._last_run[0] == n
-    compare("bf16x2 700x520 H130 run-to-stop", pg, po, {k_: 10 * v for k_, v in tol.items()})
+    compare("bf16x2 700x520 H130 run-to-stop", pg, po, dict(default=8e-5, sigma2=1.1e-5))   # measured: SigmaB 2.4e-5, sigma2 3.4e-6
     assert abs(pg._last_run[1] - d) <= 3e-2 * d + D_ATOL
 
 
@@ -444,7 +506,9 @@ def test_stream_geometry_forced(pkg, monkeypatch, geometry, mode, L, M, H):
     pg = to_pkg_params(pkg, po)
     pkg.vbmf_(Ys, pg, 3, eps=0.0, est_covs=True, est_var=True)
     _, n, d = O.vbmf_(Ys, po, 3, eps=0.0, est_covs=True, est_var=True)
-    compare(f"{geometry} geometry {mode} {L}x{M} H{H} run3", pg, po, {k: 6 * v for k, v in tol.items()})
+    # measured worst fields: f32 BHat 1.7e-5, sigma2 1.8e-6; bf16x2 BHat 1.3e-4 (3000 x 1300, narrow), sigma2 2.7e-6
+    compare(f"{geometry} geometry {mode} {L}x{M} H{H} run3", pg, po,
+            dict(default=6e-5, sigma2=6e-6) if mode == "f32" else dict(default=4e-4, sigma2=9e-6))
     assert pg._last_run[0] == 3 and abs(pg._last_run[1] - d) <= 5e-3 * d + D_ATOL
 
 

@@ -120,3 +120,39 @@ def test_epilogue_handoff_timeout_is_reported(pkg):
         it, d2, _ = c.run(3, eps=0.0, est_covs=True, est_var=True)
         again = c.get_state()
         assert it == 3 and d2 == d and np.array_equal(again["BHat"], ok["BHat"])
+
+
+def test_parity_asserts_catch_a_tenfold_regression(pkg):
+    """The parity asserts are meant to fail on a 10x regression, not only on a broken kernel: scale the SigmaB / sigma2 table the
+    B update multiplies by (vbmf_debug_set, VBMF_DEBUG_SIGMA_B_PPM) by 1 + 1e-4 -- ten times the ~1e-5 the three-sweep comparison
+    measures on BHat -- and the same comparison that passes un-perturbed must raise, from the stated tolerance or from the
+    measured-baseline guard of helpers.report()."""
+    from tests import helpers
+    from oracle import vbmf_oracle as O
+    L, M, H = 777, 555, 64
+    rng = np.random.default_rng(364)
+    Y, _, _ = O.toy_matrix(L, M, 8, 0.05, rng)
+    Yf = Y.astype(np.float32).astype(np.float64)
+    p0 = O.vbmf_init(Yf, H, ca=0.1, cb=0.1, sigma2=0.1, rng=np.random.default_rng(365))
+    A0, B0 = p0.AHat.copy(), p0.BHat.copy()
+    z = np.zeros((H, H))
+    O.vbmf_(Yf, p0, 3, eps=0.0, est_covs=True, est_var=True)
+
+    def errs_of(ppm):
+        with pkg.capi.Context(L, M, H, y_dtype=pkg.VBMF_Y_F32) as c:
+            c.set_Y(Yf)
+            c.debug_set(pkg.capi.DEBUG_SIGMA_B_PPM, ppm)
+            c.set_state(A0, B0, z, z, 0.1 * np.ones(H), 0.1 * np.ones(H), 0.1)
+            c.run(3, eps=0.0, est_covs=True, est_var=True)
+            s = c.get_state()
+        return dict(BHat=helpers.relF(s["BHat"], p0.BHat), AHat=helpers.relF(s["AHat"], p0.AHat),
+                    SigmaB=helpers.relF(s["SigmaB"], p0.SigmaB))
+
+    clean = errs_of(0)
+    helpers.report("soak 777x555 H64 f32 run3 clean: " + " ".join(f"{k}={v:.2e}" for k, v in clean.items()))
+    assert clean["BHat"] < 1e-4 and clean["AHat"] < 5e-5, clean            # measured: BHat 3.1e-5, AHat 8.3e-6
+    bad = errs_of(100)
+    assert bad["BHat"] > 3 * max(clean["BHat"], 1e-5), (clean, bad)        # the perturbation is visible ...
+    line = "f32 777x555 H64 run3: " + " ".join(f"{k}={v:.2e}" for k, v in bad.items())
+    with pytest.raises(AssertionError):                                    # ... and the guard under every comparison catches it
+        helpers.baseline_guard(line)

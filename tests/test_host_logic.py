@@ -56,3 +56,24 @@ def test_fingerprint_and_default_dtype(pkg):
     f0 = pkg._fingerprint(big)
     big += 1.0
     assert pkg._fingerprint(big) != f0
+
+
+def test_parity_baseline_guard():
+    """The measured-error baseline under every GPU comparison (tests/helpers.py): within 3x of the measured figure passes,
+    a tenfold regression on one field fails, unknown tags and non-comparison lines are ignored."""
+    import json
+    import os
+    import pytest
+    from tests import helpers
+    base = json.load(open(helpers.BASELINE))
+    tag = "f32 777x555 H64 run3"
+    assert tag in base and base[tag]["BHat"] > 0
+    ok = f"{tag}: " + " ".join(f"{k}={2.5 * v:.2e}" for k, v in base[tag].items())
+    helpers.baseline_guard(ok)
+    bad = f"{tag}: " + " ".join(f"{k}={(10 * v if k == 'SigmaB' else v):.2e}" for k, v in base[tag].items())
+    with pytest.raises(AssertionError, match="SigmaB"):
+        helpers.baseline_guard(bad)
+    helpers.baseline_guard("no such tag: A=1.00e+00")
+    helpers.baseline_guard("   d trace: max abs dev 4.76e-07 at sweep 0")
+    tiny = f"{tag}: SigmaA={helpers.BASELINE_FLOOR * 0.9:.2e}"          # below the noise floor: never a regression
+    helpers.baseline_guard(tiny)

@@ -36,7 +36,7 @@ SYMBOLS = [
     "vbmf_sparse_lower_bound_trimmed", "vbmf_debug_set",
 ]
 VBMF_OK, VBMF_ERR_INVALID, VBMF_ERR_NO_DEVICE, VBMF_ERR_HIP, VBMF_ERR_NUMERIC, VBMF_ERR_COMM, VBMF_ERR_UNSUPPORTED, VBMF_ERR_SYNC = 0, -1, -2, -3, -4, -5, -6, -7
-DEBUG_EPI_SPIN_LIMIT, DEBUG_EPI_EXPECT_SKEW = 0, 1
+DEBUG_EPI_SPIN_LIMIT, DEBUG_EPI_EXPECT_SKEW, DEBUG_SIGMA_B_PPM = 0, 1, 2
 SSTEP_A, SSTEP_B, SSTEP_CA, SSTEP_CB, SSTEP_SIGMA, SSTEP_PRIORS = 1, 2, 4, 8, 16, 32
 PEEK_P, PEEK_Q, PEEK_A32, PEEK_B32, PEEK_FA, PEEK_FB, PEEK_Y1, PEEK_Y2, PEEK_DIMS, PEEK_CHAIN = range(10)
 
@@ -282,11 +282,24 @@ class Context:
     def step(self, which):
         self._chk(self._lib.vbmf_step(self._h, which))
 
+    def note(self):
+        """The library's note on the last call that returned OK ('' if none): vbmf_last_error after success carries e.g. the
+        'eps below the resolution of d' remark of vbmf_run (include/vbmf_hip.h)."""
+        m = self._lib.vbmf_last_error(self._h).decode()
+        return m if m.startswith("note:") else ""
+
+    def _warn_note(self):
+        m = self.note()
+        if m:
+            import warnings
+            warnings.warn(m, RuntimeWarning, stacklevel=3)
+
     def run(self, niter, eps=1e-6, est_covs=False, est_var=False, want_trace=False):
         it = C.c_int64(); d = C.c_double()
         tr = np.zeros((max(niter, 1), 4)) if want_trace else None
         self._chk(self._lib.vbmf_run(self._h, niter, eps, int(est_covs), int(est_var), C.byref(it), C.byref(d),
                                      _dptr(tr)))
+        self._warn_note()
         return it.value, d.value, (tr[:it.value] if want_trace else None)
 
     def run_fixed_basis(self, niter):
@@ -340,6 +353,7 @@ class Context:
         it = C.c_int64(); d = C.c_double()
         tr = np.zeros((max(niter, 1), 4)) if want_trace else None
         self._chk(self._lib.vbmf_sparse_run(self._h, niter, eps, int(est_cb), C.byref(it), C.byref(d), _dptr(tr)))
+        self._warn_note()
         return it.value, d.value, (tr[:it.value] if want_trace else None)
 
     def sparse_set_noise_rows(self, sigmaVecHat, zetaVec, etaVec):

@@ -40,7 +40,7 @@ struct StateLayout {
 enum : int { S_SIGMA2 = 0, S_TRYY, S_LOGDET_SA, S_LOGDET_SB, S_LAMB_PREV, S_LAMB_NEW, S_LAMD, S_D, S_ELBO,
              S_TRDOT, S_RESID, S_TRYBA,
              S_LOGDET_SA_SHADOW = 20 };      // 12..18: sparse_kernels.hpp
-enum : int { I_STOP = 0, I_ITERS = 1, I_ERR = 2, I_NITER = 3, I_SREADY = 4 };
+enum : int { I_STOP = 0, I_ITERS = 1, I_ERR = 2, I_NITER = 3, I_SREADY = 4, I_DBG_SB_PPM = 5 };   // (5: test hook, vbmf_debug_set)
 
 // Threads of the workgroup that run the control algebra: the whole block -- except in the 512-thread launch of the H >= 128
 // streaming kernel (stream_gemm.hpp, stream_lds8_kernel), whose control workgroups run on their first 256 threads (waves 4-7
@@ -352,6 +352,21 @@ __device__ __forceinline__ int load_stop(const int* ints) {
     return __hip_atomic_load(ints + I_STOP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Row-sharded runs: the ranks' error flags travel as one more number of the packed Gram message (post_kernels.hpp,
+// publish_err_flag) and arrive summed at st[GX + 1]; every rank's loop test reads the same sum, so a hand-off timeout or a bad
+// pivot on ONE rank stops EVERY rank at the same sweep (without it the other ranks ran on into the all-reduce with that rank's
+// garbage partials).  Returns 0, or the error code this rank records if it has none of its own: 2 (hand-off) / 1 (numeric).
+__device__ __forceinline__ int remote_error_code(const double* __restrict__ st, StateLayout lay) {
+    const double f = st[lay.GX() + 1];
+    return f >= 1000.0 ? 2 : (f > 0.0 ? 1 : 0);
+}
+__device__ __forceinline__ bool stop_on_remote_error(const double* __restrict__ st, StateLayout lay, int* __restrict__ ints) {
+    const int rc = remote_error_code(st, lay);
+    if (rc == 0) return false;
+    if (atomicCAS(ints + I_ERR, 0, rc) == 0) atomicOr(ints + I_ERR, 0x200);   // 0x200: no error of this rank's own -- another rank's
+    return true;
+}
+
 // Inverse of an SPD matrix of order H <= 16 NB in LDS by the FOUR waves of a 256-thread control workgroup (blk_inverse.hpp:
 // blocked symmetric sweep, the 16 x 16 diagonal blocks inside a wavefront, rank-16 updates on the fp64 MFMA, two barriers per
 // BLOCK step where round 2's register-tiled Gauss-Jordan had a barrier and two LDS round trips per pivot).
@@ -430,11 +445,12 @@ __device__ __forceinline__ void ctrl_cov_dev(double* __restrict__ st, StateLayou
             if (i == j) v += sigma2 / cdiag[i];
             return v;
         }, &ldK, &badK);
+        const double dbg = which == 1 ? 1.0 + 1e-6 * (double)ints[I_DBG_SB_PPM] : 1.0;      // test hook (normally exactly 1)
         for (int t = threadIdx.x; t < Hp * Hp; t += 256) {
             const int i = t / Hp, j = t % Hp;
             const double v = (i < H && j < H) ? spd_inv_at<NBc>(lds, i, j) : 0.0;
             Sself[(long long)i * Hp + j] = sigma2 * v;
-            S32[(long long)i * Hp + j] = (float)v;                  // Sigma/sigma2: what the post kernel multiplies by
+            S32[(long long)i * Hp + j] = (float)(v * dbg);          // Sigma/sigma2: what the post kernel multiplies by
         }
         if (badK) atomicExch(ints + I_ERR, 1);
         if (threadIdx.x == 0)
@@ -597,11 +613,18 @@ __global__ __launch_bounds__(256) void eig_kernel(double* __restrict__ st, State
 // H > 128 (the squaring kernel's two LDS tiles do not fit): power iteration with the matrix held in REGISTERS.
 // 1024 threads; thread (row = t/4, q = t%4) keeps G[row][64q .. 64q+63] / tr as 64 floats, the vector lives
 // in LDS (double-buffered: one barrier per iteration, normalised every 4th).  lambda = Rayleigh quotient of the
-// final vector, accumulated in fp64.  Converges like (lambda_2/lambda_1)^(2k) in the quotient;
-// EIG_POWER_ITERS fixed, so near-degenerate top eigenvalues are only resolved to ~1e-3 -- accepted (d is a
-// stopping heuristic), stated in DESIGN.md.  (The first version walked the fp64 matrix in global memory every
-// iteration: 31 us per iteration, 3 ms per call at H = 256; this one is ~0.5 us per iteration.)
-constexpr int EIG_POWER_ITERS = 128;
+// final vector, accumulated in fp64.  Converges like (lambda_2/lambda_1)^(2k) in the quotient.  (The first version walked the
+// fp64 matrix in global memory every iteration: 31 us per iteration, 3 ms per call at H = 256; this one is ~0.5 us per
+// iteration.  Round 2 ran a fixed 128 steps, which resolved near-degenerate top eigenvalues to ~1e-3 only.)
+// Round 3: the iteration runs to a TOLERANCE, not a fixed count.  Every fourth step the vector is normalised anyway, and the
+// norm it is divided by is ||G^4 v|| -> lambda^4: lam = (||G^4 v||^2)^(1/8) is an eigenvalue estimate that costs nothing.  The loop
+// ends when two successive estimates differ by <= EIG_POWER_TOL lam AND the geometric extrapolation of the remaining error
+// (diff * r / (1 - r), r = ratio of successive differences) is below the same bound -- so a slowly converging spectrum (top
+// eigenvalues 0.1 % apart: r ~ 0.99) is iterated on, up to EIG_POWER_MAX_ITERS steps, where the fixed 128 steps of round 2 left
+// ~1e-3; a well-separated one stops after 8-24 steps instead of 128 (this kernel sits beside -- at H = 256, since round 3's
+// streaming kernel, in FRONT of -- the Y'B pass: 0.8 ms for its 128 steps inside a pass).
+constexpr int EIG_POWER_MAX_ITERS = 2048;
+constexpr double EIG_POWER_TOL = 1e-6;
 __global__ __launch_bounds__(1024) void eig_power_kernel(double* __restrict__ st, StateLayout lay, int H, int spectral,
                                                          int do_d, int do_b, const int* __restrict__ ints) {
     __shared__ double red[16];
@@ -634,7 +657,8 @@ __global__ __launch_bounds__(1024) void eig_power_kernel(double* __restrict__ st
     if (threadIdx.x < 256) vbuf[0][threadIdx.x] = threadIdx.x < H ? (float)(G[(long long)threadIdx.x * Hp + threadIdx.x] / tr) + 1e-3f : 0.f;
     __syncthreads();
     int cur = 0;
-    for (int it = 0; it < EIG_POWER_ITERS; ++it) {
+    double lam_prev = 0.0, diff_prev = 0.0;
+    for (int it = 0; it < EIG_POWER_MAX_ITERS; ++it) {
         const float4* v4 = reinterpret_cast<const float4*>(&vbuf[cur][q * 64]);
         float acc = 0.f;
 #pragma unroll
@@ -644,14 +668,25 @@ __global__ __launch_bounds__(1024) void eig_power_kernel(double* __restrict__ st
         }
         acc += __shfl_xor(acc, 1);
         acc += __shfl_xor(acc, 2);
+        bool done = false;
         if ((it & 3) == 3) {                                    // entries shrink by >= 1/256 per step: safe for 4
             double n1 = (q == 0) ? (double)acc * (double)acc : 0.0;
             n1 = block_sum(n1, red);
             acc = n1 > 0.0 ? (float)((double)acc / sqrt(n1)) : 0.f;
+            // (block_sum hands every thread the same n1: the test below is uniform)
+            const double lam = sqrt(sqrt(sqrt(n1)));            // (||G^4 v||^2)^(1/8), v normalised four steps ago (it >= 7)
+            const double diff = fabs(lam - lam_prev);
+            if (it >= 15) {                                     // lam is meaningful from it = 7, diff from 11, r from 15
+                const double r = diff_prev > 0.0 ? diff / diff_prev : 0.0;
+                const double rest = r < 0.999 ? diff * r / (1.0 - r) : 1.0;      // geometric tail of the remaining corrections
+                done = !(n1 > 0.0) || (diff <= EIG_POWER_TOL * lam && rest <= EIG_POWER_TOL * lam);
+            }
+            lam_prev = lam; diff_prev = diff;
         }
         if (q == 0) vbuf[cur ^ 1][row] = acc;
         __syncthreads();
         cur ^= 1;
+        if (done) break;
     }
     // Rayleigh quotient v'Gv / v'v, fp64 accumulation
     double gv = 0.0;
@@ -757,7 +792,8 @@ __device__ __forceinline__ void ctrl_end_dev(double* __restrict__ st, StateLayou
             const int it = ints[I_ITERS];
             if (trace) { trace[4 * it + 0] = d; trace[4 * it + 1] = sigma2; trace[4 * it + 2] = F; trace[4 * it + 3] = resid; }
             ints[I_ITERS] = it + 1;
-            if (!(d > eps) || it + 1 >= ints[I_NITER])                     // src/vbmf.jl:193 (NaN d exits too)
+            const bool rerr = stop_on_remote_error(st, lay, ints);
+            if (!(d > eps) || it + 1 >= ints[I_NITER] || rerr)            // src/vbmf.jl:193 (NaN d exits too)
                 __hip_atomic_store(ints + I_STOP, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
@@ -803,7 +839,8 @@ __device__ __forceinline__ void ctrl_loop_dev(double* __restrict__ st, StateLayo
         scal[S_D] = d;
         if (trace) trace[4 * it_row + 0] = d;
         ints[I_ITERS] = it_row + 1;
-        if (!(d > eps) || it_row + 1 >= ints[I_NITER])                      // NaN d exits too
+        const bool rerr = stop_on_remote_error(st, lay, ints);
+        if (!(d > eps) || it_row + 1 >= ints[I_NITER] || rerr)              // NaN d exits too
             __hip_atomic_store(ints + I_STOP, it_row + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // non-zero = stop; the
                                                                             // value names the sweep (see ctrl_end_dev)
     }

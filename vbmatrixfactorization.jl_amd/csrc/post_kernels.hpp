@@ -981,18 +981,28 @@ __device__ __forceinline__ void fold_wave_dots(const double* __restrict__ trpart
     }
 }
 
+// This rank's device error state as one more number of the packed Gram message of a row-sharded run (summed over the ranks by
+// the same all-reduce, read by every rank's loop test: ctrl_kernels.hpp, remote_error_code): 1 per numeric error (a pivot),
+// 1000 per in-launch hand-off timeout, 0 otherwise.  `ints` = the context's flag block (I_ERR at [2]).
+__device__ __forceinline__ void publish_err_flag(const int* __restrict__ ints, double* __restrict__ outErr) {
+    const int e = __hip_atomic_load(ints + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *outErr = e == 0 ? 0.0 : (e == 2 ? 1000.0 : 1.0);
+}
+
 template <int NH>
 __global__ __launch_bounds__(1024) void pair_slab_reduce_kernel(const float* __restrict__ slabs, int nslab,
                                                                 double* __restrict__ outG, double* __restrict__ outD,
                                                                 const int* __restrict__ stop,
                                                                 const double* __restrict__ trpart = nullptr, int ntr = 0,
-                                                                double* __restrict__ outTr = nullptr) {
+                                                                double* __restrict__ outTr = nullptr,
+                                                                double* __restrict__ outErr = nullptr) {
     constexpr int Hp = NH * 32;
     constexpr int NPAIR = NH * (NH + 1) / 2;
     constexpr int NOUT = 2 * NPAIR * 1024;
     constexpr int NG = 16;
     __shared__ double part[NG][64];
     if (stop && *stop) return;
+    if (outErr != nullptr && stop != nullptr && blockIdx.x == 0 && threadIdx.x == 0) publish_err_flag(stop, outErr);   // (stop = ints + I_STOP = ints)
     if (outTr != nullptr && blockIdx.x == gridDim.x - 1) fold_wave_dots(trpart, ntr, outTr);
     const int j = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int idx = blockIdx.x * 64 + j;                       // (mat, pair, r, lane) flat, grid = NOUT/64
@@ -1346,12 +1356,14 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restric
                                                           double* __restrict__ outG, double* __restrict__ outD,
                                                           const int* __restrict__ stop,
                                                           const double* __restrict__ trpart = nullptr, int ntr = 0,
-                                                          double* __restrict__ outTr = nullptr) {
+                                                          double* __restrict__ outTr = nullptr,
+                                                          double* __restrict__ outErr = nullptr) {
     // 32 consecutive elements per workgroup x 8 chunk groups: thread (e, g) sums chunks g, g + 8, ... (four loads in flight
     // at a time), the groups are then combined in fixed order through LDS.  (One thread walking all the chunks was a chain
     // of dependent-latency loads: 67 us for 245 chunks at 125k x 128.)
     __shared__ double part[8][32];
     if (stop && *stop) return;
+    if (outErr != nullptr && stop != nullptr && blockIdx.x == 0 && threadIdx.x == 0) publish_err_flag(stop, outErr);
     if (outTr != nullptr && blockIdx.x == gridDim.x - 1) fold_wave_dots(trpart, ntr, outTr);
     const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
     const int i = blockIdx.x * 32 + e;                         // grid = ceil(2n / 32)

@@ -684,7 +684,8 @@ __global__ __launch_bounds__(1024) void sparse_ctrl_end_kernel(double* __restric
             const int it = ints[I_ITERS];
             if (trace) { trace[4 * it + 0] = d; trace[4 * it + 1] = scal[S_SIGMA2]; trace[4 * it + 2] = 0.0; trace[4 * it + 3] = scal[S_ZETA]; }
             ints[I_ITERS] = it + 1;
-            if (!(d > eps) || it + 1 >= ints[I_NITER])
+            const bool rerr = stop_on_remote_error(st, lay, ints);       // row-sharded: another rank's (or this rank's) device error
+            if (!(d > eps) || it + 1 >= ints[I_NITER] || rerr)
                 __hip_atomic_store(ints + I_STOP, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }

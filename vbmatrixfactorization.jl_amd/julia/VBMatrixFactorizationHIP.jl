@@ -83,6 +83,13 @@ function chk(h::Ptr{Cvoid}, rc::Cint)
     error("vbmf_hip error $rc: $msg")          # the reference signals errors with error(...), src/util.jl:116
 end
 
+# after a call that returned OK: the library's note, if any (vbmf_last_error text starting with "note:", e.g. vbmf_run's remark on an
+# eps below what d resolves on the device -- include/vbmf_hip.h), becomes a warning
+function warn_note(h::Ptr{Cvoid})
+    msg = unsafe_string(ccall((:vbmf_last_error, libvbmf), Cstring, (Ptr{Cvoid},), h))
+    startswith(msg, "note:") && @warn msg
+end
+
 const _cache = Dict{UInt,Ctx}()
 
 # fp32 storage of the caller's Float64 Y by default; ENV["VBMF_HIP_Y"] = "bf16" opts into bf16 storage (the BASELINE headline
@@ -220,6 +227,7 @@ function vbmf!(Y::Array{Float64,2}, params::vbmf_parameters, niter::Int; eps::Fl
     chk(c.h, ccall((:vbmf_run, libvbmf), Cint,
         (Ptr{Cvoid}, Int64, Float64, Cint, Cint, Ref{Int64}, Ref{Float64}, Ptr{Float64}),
         c.h, niter, eps, est_covs, est_var, iters, d, C_NULL))
+    warn_note(c.h)
     pull!(c, params)
     params.L * params.M <= (1 << 24) && updateYHat!(params)                                   # :217
     verb && print("Factorization finished after ", iters[], " iterations, eps = ", d[], "\n")  # :221
