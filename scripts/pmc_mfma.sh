@@ -11,7 +11,7 @@ R=$GRAFT_REPO_ROOT
 d=$R/gpurun_out/pmc_mfma_$CFG
 rm -rf $d
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES \
-  --kernel-trace --output-format csv -d $d -- python3 $R/bench.py --config $CFG --steps 6 --warmup 2 --no-cpu-baseline --settle-seconds 0 > $d.log 2>&1 \
+  --kernel-trace --output-format csv -d $d -- python3 $R/bench.py --config $CFG --steps 6 --warmup 2 $PMC_EXTRA --no-cpu-baseline --settle-seconds 0 > $d.log 2>&1 \
   || { echo "rocprofv3 failed"; tail -5 $d.log; exit 1; }
 python3 - <<PY
 import csv, glob, collections, json, os

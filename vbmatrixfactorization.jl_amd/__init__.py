@@ -190,12 +190,24 @@ _FP_FULL, _FP_SAMPLE = 1 << 22, 1 << 16
 
 
 def _fingerprint(Y):
+    """Content fingerprint of the caller's matrix (whole matrix up to _FP_FULL elements, a strided sample beyond).  Compared as
+    BYTES: the CRC of the sampled values, plus two sums kept as bit patterns so that a matrix holding NaN still equals itself
+    (NaN != NaN would re-upload it on every call).  A non-contiguous Y (a sliced view) is sampled through its strides -- no copy
+    of the matrix is made to take the fingerprint."""
     import zlib
-    flat = Y.ravel(order="K")                  # a view for C- or F-contiguous arrays
-    if flat.size > _FP_FULL:
-        flat = flat[::max(1, flat.size // _FP_SAMPLE)]
-    flat = np.ascontiguousarray(flat)
-    return (float(flat.sum()), float(np.abs(flat).sum()), zlib.crc32(flat.tobytes()))
+    if Y.flags.c_contiguous or Y.flags.f_contiguous:
+        flat = Y.ravel(order="K")              # a view
+        if flat.size > _FP_FULL:
+            flat = flat[::max(1, flat.size // _FP_SAMPLE)]
+    elif Y.size > _FP_FULL:
+        # sample rows and columns by strides of the view itself (~_FP_SAMPLE elements), then copy only the sample
+        step = max(1, int(np.sqrt(Y.size / _FP_SAMPLE)))
+        flat = Y[::step, ::step]
+    else:
+        flat = Y
+    flat = np.ascontiguousarray(flat).reshape(-1)
+    sums = np.array([flat.sum(), np.abs(flat).sum()], dtype=np.float64)
+    return (sums.tobytes(), zlib.crc32(flat.tobytes()))
 
 
 def invalidate(Y=None):
@@ -434,11 +446,25 @@ def _sparse_ctx(Y, p, diag_var=False, dual=False, trial=False):
     """Y = None: the updates whose reference signatures take no Y (updateCA!, updateCB!: src/vbmf_sparse.jl:284-300 and the
     grouped models' twins) -- a cached context of the same problem serves, else one that is never given a matrix."""
     if Y is None:
+        # updateCA! / updateCB! do not depend on the noise model: ANY cached context of this problem and grouping serves, whatever
+        # its diag_var (a heteroscedastic step-wise loop would otherwise evict -- and re-upload -- its own Y-holding session on every
+        # CA / CB call), and a context that holds no matrix lives in its own slot instead of closing the ones that do
         want = (int(p.H), bool(diag_var), bool(dual), bool(trial), tuple(sorted(_defaults.items())))
         for k, v in _sparse_sessions.items():
-            if k[1] == (p.L, p.M) and k[3:] == want:
+            if k[1] == (p.L, p.M) and k[3] == want[0] and k[5:] == want[2:]:
                 return v[0]
         key = ("noY", (p.L, p.M), 0) + want
+        if trial:
+            variant = VBMF_VARIANT_TRIAL_DIAG
+        elif dual:
+            variant = VBMF_VARIANT_DUAL_DIAG
+        else:
+            variant = VBMF_VARIANT_SPARSE_DIAG
+        for k in [k for k in _sparse_sessions if k[0] == "noY"]:
+            _sparse_sessions.pop(k)[0].close()
+        c = Context(p.L, p.M, p.H, variant=variant, **_defaults)
+        _sparse_sessions[key] = (c, lambda: None, None)
+        return c
     else:
         Y = np.asarray(Y, dtype=np.float64)
         if Y.ndim != 2:
@@ -451,7 +477,7 @@ def _sparse_ctx(Y, p, diag_var=False, dual=False, trial=False):
                 ent[0].set_Y(Y)
                 _sparse_sessions[key] = (ent[0], ent[1], fp)
             return ent[0]
-    for k in list(_sparse_sessions):
+    for k in [k for k in _sparse_sessions if k[0] != "noY"]:
         _sparse_sessions.pop(k)[0].close()
     if trial:
         variant = VBMF_VARIANT_TRIAL_DIAGVAR if diag_var else VBMF_VARIANT_TRIAL_DIAG
@@ -459,10 +485,6 @@ def _sparse_ctx(Y, p, diag_var=False, dual=False, trial=False):
         variant = VBMF_VARIANT_DUAL_DIAGVAR if diag_var else VBMF_VARIANT_DUAL_DIAG
     else:
         variant = VBMF_VARIANT_SPARSE_DIAGVAR if diag_var else VBMF_VARIANT_SPARSE_DIAG
-    if Y is None:
-        c = Context(p.L, p.M, p.H, variant=variant, **_defaults)
-        _sparse_sessions[key] = (c, lambda: None, None)
-        return c
     c = Context(Y.shape[0], Y.shape[1], p.H, variant=variant, **_defaults)
     c.set_Y(Y)
     _sparse_sessions[key] = (c, weakref.ref(Y), fp)

@@ -9,8 +9,12 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# VBMF_HIP_LIB: another build of the SAME library (A/B tuning builds under variants/); default: the in-tree build
+# VBMF_HIP_LIB: another build of the SAME library (A/B tuning builds under variants/); default: the in-tree build.
+# An override must exist and export every symbol of include/vbmf_hip.h (lib() binds them all and fails loudly otherwise); it is NOT
+# covered by build.py's source-hash stamp -- whoever builds a variant is responsible for building it from the current sources.
 LIB_PATH = os.environ.get("VBMF_HIP_LIB") or os.path.join(_HERE, "libvbmf_hip.so")
+if os.environ.get("VBMF_HIP_LIB") and not os.path.isfile(LIB_PATH):
+    raise FileNotFoundError(f"VBMF_HIP_LIB={LIB_PATH}: no such library (A/B variant builds: scripts/README.md)")
 
 VBMF_Y_F32, VBMF_Y_BF16 = 0, 1
 VBMF_FACTOR_AUTO, VBMF_FACTOR_BF16, VBMF_FACTOR_BF16X2 = 0, 1, 2

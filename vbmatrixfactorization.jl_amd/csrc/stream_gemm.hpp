@@ -124,9 +124,12 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const uint4* __restric
     int xg = xb * 4 + wib;
     bool active = true;
     int t0 = xg * NXW_, nt = NXW_;                         // first x tile of this wave, number of its tiles
+    __shared__ int epi_abort;                              // EPI: a wave's hand-off wait expired (see the epilogue)
     if constexpr (EPI) {
         // every wave of the workgroup meets in the epilogue's fold: a wave without tiles streams nothing
         if (split >= nsplit) return;                       // workgroup-uniform
+        if (threadIdx.x == 0) epi_abort = 0;
+        __syncthreads();
         const int gb = epi.g_base + (xb < epi.g_rem ? 1 : 0);              // x groups of this workgroup
         xg = xb * epi.g_base + (xb < epi.g_rem ? xb : epi.g_rem) + wib;
         active = wib < gb;
@@ -265,7 +268,10 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const uint4* __restric
             int spins = 0;
             while (__hip_atomic_load(epi.sready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epi.expect) {
                 __builtin_amdgcn_s_sleep(16);
-                if (++spins > epi.spin_limit) { if (lane == 0) atomicExch(epi.err, 2); break; }    // never hang the device
+                if (++spins > epi.spin_limit) {                                                    // never hang the device
+                    if (lane == 0) { atomicExch(epi.err, 2); atomicExch(&epi_abort, 1); }
+                    break;
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
@@ -275,6 +281,11 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const uint4* __restric
         __shared__ __attribute__((aligned(16))) float stab[sigma_lds_floats<MODE, NH>()];
         load_sigma_table<MODE, NH>(stab, epi.S);
         __syncthreads();
+        // The table never came (VBMF_ERR_SYNC): leave -- workgroup-uniformly, the flag is in LDS -- WITHOUT running the tile
+        // body: the previous factor's operand tiles, the fp32 factor and the Gram slabs keep their last valid contents instead of
+        // being overwritten with products of a stale table (round 2 went on and destroyed them; the host reported the error
+        // either way, but a caller that caught it was left with a corrupted device state).
+        if (epi_abort) return;
         const unsigned long long e1 = wall_clock64();
         f32x16 G[NPAIR], D[NPAIR];
 #pragma unroll

@@ -971,9 +971,13 @@ static int device_err_status(vbmf_ctx* c, int e) {
     // bit 0x200: this rank's own kernels completed -- the error arrived with the packed Gram message of a row-sharded run
     // (ctrl_kernels.hpp, stop_on_remote_error): every rank stops at the same sweep and returns the same error class
     const char* where = (e & 0x200) ? " (reported by another rank of the row-sharded run; every rank stopped at that sweep)" : "";
-    if ((e & 0xff) == 2)
+    if ((e & 0xff) == 2) {
+        // the epilogue left without touching B (stream_gemm.hpp), but A, SigmaA and the control scalars of that sweep are already
+        // written: the device state is a mixture -- the handle asks for vbmf_set_state before it steps or runs again
+        c->haveState = false;
         FAIL(c, VBMF_ERR_SYNC, "in-launch hand-off timed out: the Y*A pass's register epilogue gave up waiting for the SigmaB "
-                               "table of its own launch (bounded spin); this sweep's state is not valid%s", where);
+                               "table of its own launch (bounded spin); this sweep's state is not valid, set the state again%s", where);
+    }
     FAIL(c, VBMF_ERR_NUMERIC, "non-positive or non-finite pivot while inverting an H x H posterior precision%s", where);
 }
 
