@@ -890,6 +890,146 @@ __device__ __forceinline__ void ctrl_chain(const CtrlArgs& a, void* lds, int par
     }
 }
 
+// ---- vbls! as H x H algebra (examples/mil_util.jl:179-203, vbmf_parameters branch, no label mask) ----------------------------
+// With B, SigmaB, CB frozen, P = Y'B is fixed, and so is S = P'P.  One iteration of  updateA!; updateCA!; updateSigma2!  then needs
+// no M- or L-sized work at all:
+//     K      = B'B + L SigmaB + sigma2 inv(CA)          SigmaA = sigma2 inv(K)                       (src/vbmf.jl:96-97)
+//     A'A    = SigmaA S SigmaA / sigma2^2               (A = P SigmaA / sigma2, src/vbmf.jl:98)
+//     CA_hh  = (A'A)_hh / M + SigmaA_hh                                                               (src/vbmf.jl:129-134)
+//     tr(Y'BA') = tr(S SigmaA) / sigma2
+//     sigma2 = (||Y||^2 - 2 tr(Y'BA') + tr((A'A + M SigmaA)(B'B + L SigmaB))) / (L M)                 (src/vbmf.jl:153-157)
+// so the whole loop is ONE launch of one workgroup: the inverse by the blocked sweep, the two H x H products on the fp64 MFMA,
+// everything LDS-resident, and A itself is formed once at the end from the last inv(K).  The MIL classifier calls vbls! with 150
+// iterations on bags of a few tens of columns and H <= 10 (examples/mil_util.jl:473-479): per call 5.6-7.6 ms with one launch
+// group per iteration (profiles/r03_f_vbls_mil.txt: break-even with NumPy on the host), most of it launch latency.
+// 256 threads; LDS: four 16 NB x (16 NB + 2) fp64 images (W, S, SigmaA, T).  Blocks (I, J) are owned by wave (I NB + J) % 4.
+// Reads GB, SB, ca, sigma2, ||Y||^2 and S (at st + lay.W1()); writes SA, ca, sigma2, log det SigmaA and the fp32 table inv(K).
+template <int NB>
+__global__ __launch_bounds__(256) void vbls_loop_kernel(double* __restrict__ st, StateLayout lay, int H, double Lg, double M,
+                                                        int niter, float* __restrict__ SA32, int* __restrict__ ints) {
+    extern __shared__ __attribute__((aligned(16))) double lds_vl[];
+    __shared__ double red[16];
+    __shared__ double ca_s[16 * NB], dg_s[16 * NB];
+    constexpr int NP = 16 * NB, LD = NP + 2, IMG = NP * LD;
+    constexpr int NOWN = (NB * NB + 3) / 4;                    // blocks per wave
+    double* W = lds_vl;
+    double* Sm = lds_vl + IMG;
+    double* SAm = lds_vl + 2 * IMG;
+    double* Tm = lds_vl + 3 * IMG;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c16 = lane & 15, q16 = lane >> 4;
+    const int Hp = lay.Hp, nbu = (H + 15) >> 4;
+    double* scal = st + lay.scal();
+    double sigma2 = scal[S_SIGMA2];
+    const double trYY = scal[S_TRYY];
+    const double* Sg = st + lay.W1();
+    // K0 = B'B + L SigmaB of this wave's blocks (C/D layout), S into LDS, CA into LDS
+    f64x4 k0[NOWN];
+#pragma unroll
+    for (int o = 0; o < NOWN; ++o) {
+        const int b = w + 4 * o, I = b / NB, J = b % NB;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 16 * I + q16 + 4 * r, j = 16 * J + c16;
+            k0[o][r] = (b < NB * NB && i < H && j < H) ? st[lay.GB() + (long long)i * Hp + j] + Lg * st[lay.SB() + (long long)i * Hp + j] : 0.0;
+        }
+    }
+    for (int t = threadIdx.x; t < NP * NP; t += 256) {
+        const int i = t / NP, j = t % NP;
+        Sm[i * LD + j] = (i < H && j < H) ? Sg[(long long)i * Hp + j] : 0.0;
+    }
+    if (threadIdx.x < NP) ca_s[threadIdx.x] = threadIdx.x < H ? st[lay.ca() + threadIdx.x] : 1.0;
+    __syncthreads();
+    double ldK = 0.0;
+    int bad = 0;
+    for (int it = 0; it < niter; ++it) {
+        // K into the sweep image (every block: the sweep reads the upper ones)
+#pragma unroll
+        for (int o = 0; o < NOWN; ++o) {
+            const int b = w + 4 * o, I = b / NB, J = b % NB;
+            if (b >= NB * NB) continue;
+            f64x4 x = k0[o];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * I + q16 + 4 * r, j = 16 * J + c16;
+                if (i == j) x[r] = i < H ? x[r] + sigma2 / ca_s[i] : 1.0;       // + sigma2 inv(CA); identity padding
+            }
+            blk_st_rows(W, LD, I, J, lane, x);
+        }
+        __syncthreads();
+        PivAcc pv;
+        blk_sweep<NB, 4>(W, LD, nbu, w, lane, pv);               // upper blocks of W = -inv(K)
+        ldK = pv.logdet();
+        bad |= pv.bad;
+        // SigmaA = sigma2 inv(K), full symmetric image
+        for (int t = threadIdx.x; t < NP * NP; t += 256) {
+            const int i = t / NP, j = t % NP;
+            SAm[i * LD + j] = (i < H && j < H) ? -sigma2 * (i <= j ? W[i * LD + j] : W[j * LD + i]) : 0.0;
+        }
+        __syncthreads();
+        // T = SigmaA S  (blocks of this wave; SigmaA symmetric: the A operand of block (I, K) is the row read of block (K, I))
+#pragma unroll
+        for (int o = 0; o < NOWN; ++o) {
+            const int b = w + 4 * o, I = b / NB, J = b % NB;
+            if (b >= NB * NB) continue;
+            f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int K = 0; K < NB; ++K) acc = blk_mma(blk_ld_rows(SAm, LD, K, I, lane), blk_ld_rows(Sm, LD, K, J, lane), acc);
+            blk_st_rows(Tm, LD, I, J, lane, acc);
+        }
+        __syncthreads();
+        // A'A = T SigmaA / sigma2^2 and the three reductions, block by block in registers
+        const double is4 = 1.0 / (sigma2 * sigma2);
+        double t2 = 0.0, trs = 0.0;
+#pragma unroll
+        for (int o = 0; o < NOWN; ++o) {
+            const int b = w + 4 * o, I = b / NB, J = b % NB;
+            if (b >= NB * NB) continue;
+            f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int K = 0; K < NB; ++K) acc = blk_mma(blk_ld_cols(Tm, LD, I, K, lane), blk_ld_rows(SAm, LD, K, J, lane), acc);
+            const f64x4 sa = blk_ld_rows(SAm, LD, I, J, lane), ss = blk_ld_rows(Sm, LD, I, J, lane);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * I + q16 + 4 * r, j = 16 * J + c16;
+                const double ata = acc[r] * is4;
+                t2 += (ata + M * sa[r]) * k0[o][r];
+                trs += ss[r] * sa[r];
+                if (i == j && i < H) dg_s[i] = ata / M + sa[r];             // the new CA_hh
+            }
+        }
+        t2 = block_sum(t2, red);
+        trs = block_sum(trs, red);                               // (its barriers publish dg_s)
+        const bool last = it + 1 == niter;
+        if (last) {                                              // what the last updateA! leaves: SigmaA, inv(K) as the post kernel's table
+            for (int t = threadIdx.x; t < Hp * Hp; t += 256) {
+                const int i = t / Hp, j = t % Hp;
+                const double v = (i < H && j < H) ? SAm[i * LD + j] : 0.0;
+                st[lay.SA() + t] = v;
+                SA32[t] = (float)(v / sigma2);
+            }
+            if (threadIdx.x == 0) scal[S_LOGDET_SA] = (double)H * log(sigma2) - ldK;
+        }
+        __syncthreads();
+        if (threadIdx.x < NP) ca_s[threadIdx.x] = threadIdx.x < H ? dg_s[threadIdx.x] : 1.0;
+        sigma2 = (trYY - 2.0 * trs / sigma2 + t2) / (Lg * M);
+        __syncthreads();
+    }
+    if (threadIdx.x < H) st[lay.ca() + threadIdx.x] = ca_s[threadIdx.x];
+    if (threadIdx.x == 0) scal[S_SIGMA2] = sigma2;
+    if (bad) atomicExch(ints + I_ERR, 1);
+}
+
+// identity (H x H, zero-padded to Hp) as a post kernel's table: A = P I, whose Gram is S = P'P
+__global__ void identity_table_kernel(float* __restrict__ S32, int H, int Hp) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < Hp * Hp) S32[t] = ((t / Hp) == (t % Hp) && (t / Hp) < H) ? 1.f : 0.f;
+}
+__global__ void copy_doubles_kernel(const double* __restrict__ src, double* __restrict__ dst, int n) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) dst[t] = src[t];
+}
+
 __global__ void copy_scalar_kernel(double* st, StateLayout lay, int dst, int src) {
     if (threadIdx.x == 0 && blockIdx.x == 0) st[lay.scal() + dst] = st[lay.scal() + src];
 }

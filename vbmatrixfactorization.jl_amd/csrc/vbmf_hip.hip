@@ -1601,13 +1601,38 @@ int vbmf_run_fixed_basis(vbmf_ctx* c, int64_t niter) {
     if (niter < 0 || niter > (1ll << 30)) FAIL(c, VBMF_ERR_INVALID, "vbmf_run_fixed_basis: bad niter");
     HIPCHK(c, hipSetDevice(c->o.device));
     TRY(ensure_ready(c));
-    for (int64_t it = 0; it < niter; ++it) {
+    // Without a label mask the loop is H x H algebra on S = P'P (ctrl_kernels.hpp, vbls_loop_kernel): the first iteration runs the
+    // general way (it forms P = Y'B), the rest in ONE launch of one workgroup, and A is formed once at the end.  H <= 64.
+    // (VBMF_VBLS_LOOP=0: every iteration the general way -- the A/B switch of profiles/r03_f_vbls_mil.txt)
+    const char* ev = getenv("VBMF_VBLS_LOOP");
+    const bool fast = !c->has_mask && c->NH <= 2 && niter >= 3 && !(ev && atoi(ev) == 0);
+    for (int64_t it = 0; it < (fast ? 1 : niter); ++it) {
         TRY(do_update_A(c, true));
         TRY(ensure_gram_A(c));
         int f = 0;
         TRY(prepare_trYBA(c, &f));                          // P is current: the dot(P, A) branch
         TRY(launch_ctrl_end(c, 1 | 4 | f, 0.0, nullptr));
         if ((it & 63) == 63) TRY(check_device_err(c));      // bounds the launch queue
+    }
+    if (fast) {
+        const int H = (int)c->H, n2 = c->Hp * c->Hp;
+        const float* Psrc = (sharded(c) || c->d1.nsplit > 1) ? c->Pred : c->P;
+        // S = P'P: the A update with the identity as its table leaves A = P and A'A = S in the state (the Gram of what the post
+        // kernel stores, like every other Gram of the sweep)
+        hipLaunchKernelGGL(identity_table_kernel, dim3(cdiv(n2, 256)), dim3(256), 0, c->stream, c->SA32, H, c->Hp);
+        TRY(launch_post_gram(c, 0, Psrc));
+        hipLaunchKernelGGL(copy_doubles_kernel, dim3(cdiv(n2, 256)), dim3(256), 0, c->stream, c->st + c->lay.GA(), c->st + c->lay.W1(), n2);
+        const int NBv = H <= 16 ? 1 : (H <= 32 ? 2 : 4);
+        const size_t lds = (size_t)4 * (16 * NBv) * (16 * NBv + 2) * sizeof(double);
+        static bool attr4 = false;
+        if (NBv == 4 && !attr4) { hipFuncSetAttribute((const void*)vbls_loop_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr4 = true; }
+        if (NBv == 1) hipLaunchKernelGGL((vbls_loop_kernel<1>), dim3(1), dim3(256), lds, c->stream, c->st, c->lay, H, (double)c->Lg, (double)c->M, (int)(niter - 1), c->SA32, c->ints);
+        else if (NBv == 2) hipLaunchKernelGGL((vbls_loop_kernel<2>), dim3(1), dim3(256), lds, c->stream, c->st, c->lay, H, (double)c->Lg, (double)c->M, (int)(niter - 1), c->SA32, c->ints);
+        else hipLaunchKernelGGL((vbls_loop_kernel<4>), dim3(1), dim3(256), lds, c->stream, c->st, c->lay, H, (double)c->Lg, (double)c->M, (int)(niter - 1), c->SA32, c->ints);
+        HIPCHK(c, hipGetLastError());
+        TRY(launch_post_gram(c, 0, Psrc));                  // A = P SigmaA / sigma2 of the last updateA!, its tiles and A'A
+        c->gA_valid = true;
+        c->tr_valid = false;
     }
     return check_device_err(c);
 }
