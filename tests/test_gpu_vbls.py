@@ -51,6 +51,30 @@ def test_vbls_basic_device_loop(pkg, mode):
     assert relF(qg.YHat, qo.BHat @ qo.AHat.T) < 1e-3
 
 
+@pytest.mark.parametrize("H,niter", [(3, 150), (20, 40), (40, 25), (64, 12)])
+def test_vbls_hxh_loop_against_the_general_path_and_the_oracle(pkg, monkeypatch, H, niter):
+    """Without a label mask vbls! is H x H algebra on S = (Y'B)'(Y'B) (ctrl_kernels.hpp, vbls_loop_kernel): all but the first
+    iteration run in one launch.  Same end state as the general path (VBMF_VBLS_LOOP=0: every iteration with its own post /
+    Gram / dot kernels) and as the oracle's literal loop -- one, two and four 16-blocks per side."""
+    L, M, M2 = 700, 500, 230
+    Y, Y2 = _train_and_new_bag(L, M, M2, H, 400 + H)
+    pkg.set_defaults(y_dtype=pkg.VBMF_Y_F32, factor_dtype=pkg.VBMF_FACTOR_AUTO)
+    Y2s = Y2.astype(np.float32).astype(np.float64)
+    po = O.vbmf_init(Y, H, ca=0.1, cb=0.1, sigma2=0.1, rng=np.random.default_rng(15), materialize_yhat=False)
+    O.vbmf_(Y, po, 20, eps=0.0, est_covs=True, est_var=True)
+    qo = O.copy_vbmf_params(Y2s, po, rng=np.random.default_rng(16))
+    O.vbls_(Y2s, qo, niter)
+    out = {}
+    for name, env in (("loop", "1"), ("general", "0")):
+        monkeypatch.setenv("VBMF_VBLS_LOOP", env)
+        qg = pkg.copy_vbmf_params(Y2s, to_pkg_params(pkg, po), rng=np.random.default_rng(16))
+        pkg.vbls_(Y2s, qg, niter)
+        out[name] = qg
+        compare(f"vbls! {name} path H{H} x{niter}", qg, qo, dict(default=3e-4, sigma2=3e-4), fields=("AHat", "SigmaA", "CA"))
+    a, b = out["loop"], out["general"]
+    assert relF(a.AHat, b.AHat) < 2e-5 and relF(a.SigmaA, b.SigmaA) < 2e-4 and abs(a.sigma2 - b.sigma2) < 2e-4 * b.sigma2
+
+
 def test_vbls_sparse_device_loop(pkg):
     L, M, M2, H = 400, 260, 150, 5
     Y, Y2 = _train_and_new_bag(L, M, M2, H, 91)
