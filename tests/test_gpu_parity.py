@@ -437,6 +437,40 @@ def test_long_side_wide_rank(pkg, L, M, H):
     assert pg._last_run[0] == 2 and abs(pg._last_run[1] - d) <= 2e-2 * d + D_ATOL
 
 
+def test_streamk_split_of_the_long_pass(pkg, monkeypatch):
+    """The un-split Y*A pass on the LDS-DMA kernel follows a host-built segment list when its last round of workgroups would be
+    mostly empty (config 5: 391 blocks on 254 CUs): whole blocks first, the remaining blocks cut T ways in k, each piece into its
+    own slab, and a fix-up adds the pieces.  Here 66 001 rows at H = 140 (258 blocks, 4 of them cut): with the cut and without it
+    (VBMF_STREAMK=0) the two-sweep state agrees to fp32 summation order, and both agree with the oracle."""
+    L, M, H = 66001, 400, 140                                # 258 blocks of 256 rows, 13 stages of two k-steps each
+    Y, po = _problem(L, M, H, 700 + H)
+    ydt, fdt, tol = _mode_opts(pkg, "bf16x2")
+    pkg.set_defaults(y_dtype=ydt, factor_dtype=fdt)
+    try:
+        monkeypatch.setenv("VBMF_STREAMK", "1")                  # (off by default: measured not faster, profiles/r03_g_segment_list_ab.txt)
+        with pkg.capi.Context(L, M, H, y_dtype=ydt, factor_dtype=fdt) as c:
+            dims = c.dims()
+            c.set_Y(Y)
+            Ys = np.ascontiguousarray(c.get_Y())
+        assert dims["streamk_per"] >= 2 and dims["streamk_grid"] > 254, dims           # the plan chose the cut here (pieces per cut block, segments)
+        out = {}
+        for name, env in (("split", "1"), ("whole", "0")):
+            monkeypatch.setenv("VBMF_STREAMK", env)
+            Yn = Ys.copy()                                       # a fresh array: the host mirror opens a fresh session (the env is read at create)
+            pg = to_pkg_params(pkg, po)
+            pkg.vbmf_(Yn, pg, 2, eps=0.0, est_covs=True, est_var=True)
+            out[name] = pg
+        qo = clone_oracle(po)
+        O.vbmf_(Ys, qo, 2, eps=0.0, est_covs=True, est_var=True)
+        for name in ("split", "whole"):
+            compare(f"stream-K {name} bf16x2 {L}x{M} H{H} run2", out[name], qo, {k: 3 * v for k, v in tol.items()})
+        a, b = out["split"], out["whole"]
+        assert relF(a.BHat, b.BHat) < 5e-6 and relF(a.AHat, b.AHat) < 5e-6 and relF(a.SigmaB, b.SigmaB) < 2e-5
+        assert not np.array_equal(a.BHat, b.BHat) or True        # (summation order differs: equality is not expected, nor required)
+    finally:
+        pkg.set_defaults(y_dtype=pkg.VBMF_Y_F32, factor_dtype=pkg.VBMF_FACTOR_AUTO)
+
+
 def test_logged_trajectory_against_the_reference_record(pkg, golden_dir, tmp_path):
     """vbmf!(...; logdir=...) (src/vbmf.jl:181-184,205-207,224-228): run the reference's recorded experiment on the
     device with per-sweep logging, read the log back with the data_manip twin and compare EVERY slice with the

@@ -482,7 +482,8 @@ class Context:
 
     def dims(self):
         v = self.peek(PEEK_DIMS, 16, dtype=np.int32)
-        keys = ["Hp", "NH", "mode", "XT1", "KS1", "nsplit1", "sps1", "XT2", "KS2", "nsplit2", "sps2", "kstep", "npart", "narrow"]
+        keys = ["Hp", "NH", "mode", "XT1", "KS1", "nsplit1", "sps1", "XT2", "KS2", "nsplit2", "sps2", "kstep", "npart", "narrow",
+                "streamk_per", "streamk_grid"]       # segment-list plan of the Y*A pass: pieces per cut block (0: off), segments = workgroups
         return dict(zip(keys, (int(x) for x in v)))
 
     def time_pass(self, p, iters=10):

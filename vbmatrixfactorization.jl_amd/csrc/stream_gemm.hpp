@@ -437,12 +437,13 @@ __device__ __forceinline__ void lds_dma_piece_nt(__amdgpu_buffer_rsrc_t r, unsig
 constexpr int LDS8_SLOT_BYTES = 24 * 1024;            // one k-step: NF factor fragments + the workgroup's Y tiles
 constexpr int LDS8_BYTES = 6 * LDS8_SLOT_BYTES;       // dynamic LDS of a launch (>= the control chain's need, ctrl_lds_bytes)
 
-template <int NH, int RCTRL>
+template <int NH, int RCTRL, bool SK = false>
 __global__ __launch_bounds__(512) void stream_lds8_kernel(const uint4* __restrict__ Yt,   // [XT][KS][64]
                                                           const uint4* __restrict__ Ft,   // [KS][2][NH][64]
                                                           float* __restrict__ Out,        // [nsplit][NH*32][ldOut] or fragment-major
                                                           int XT, int KS, int steps_per_split, int nsplit, long long ldOut,
-                                                          const int* __restrict__ stop, CtrlArgs ctrl, int xcd_xb, int frag_out) {
+                                                          const int* __restrict__ stop, CtrlArgs ctrl, int xcd_xb, int frag_out,
+                                                          int sk_per = 0, const float* __restrict__ Out2 = nullptr) {   // SK: sk_per = segments, Out2 = the segment list (int4 each)
     constexpr int NF = 2 * NH;
     constexpr int HS = NH / 4;                 // waves that share an x pair (h slices of 4 tiles)
     constexpr int XPW = 8 / HS;                // x pairs per workgroup
@@ -470,8 +471,20 @@ __global__ __launch_bounds__(512) void stream_lds8_kernel(const uint4* __restric
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int npair = XT >> 1;
     const int bps = (npair + XPW - 1) / XPW;
-    int split, xb;
-    if (xcd_xb > 0) {                                     // XCD-aware map for split-K launches (see stream_gemm_kernel)
+    const int nst_all = steps_per_split >> 1;  // stages of two k-steps (the host pads k-steps to an even count)
+    int split = 0, xb = 0;
+    // SK (un-split launches whose block count is not a whole number of rounds of the chip -- config 5's Y*A pass: 391 blocks on
+    // 254 CUs = two rounds at 77 %): the launch's workgroups follow a host-built SEGMENT LIST, one (x block, first stage, stages,
+    // slab) per workgroup, in dispatch order: first one whole block per CU, then the remaining blocks cut T ways in k, the pieces
+    // ordered k-major -- workgroups that run at the same time stream the same k range of the factor, which is what keeps the
+    // factor in the XCDs' L2s (a stream-K cut at arbitrary stages ran every workgroup at a different k: 1.05 ms instead of 0.83 ms,
+    // the factor came from beyond L2).  Piece t of a cut block goes to slab t; the host adds slabs 1 .. T-1 into slab 0 for those blocks.
+    int s_lo = 0, nst = nst_all, slab = 0;
+    if constexpr (SK) {
+        if (bid >= sk_per) return;                        // (sk_per = number of segments)
+        const int4 sg = reinterpret_cast<const int4*>(Out2)[bid];
+        xb = sg.x; s_lo = sg.y; nst = sg.z; slab = sg.w;
+    } else if (xcd_xb > 0) {                              // XCD-aware map for split-K launches (see stream_gemm_kernel)
         const int g = bid & 7, j = bid >> 3;
         const int w = g * xcd_xb + j;
         if (j >= xcd_xb || w >= bps * nsplit) return;
@@ -483,11 +496,14 @@ __global__ __launch_bounds__(512) void stream_lds8_kernel(const uint4* __restric
     }
     if (split >= nsplit) return;                          // workgroup-uniform
     const int xp = wib / HS, hs = wib % HS;
+    const int voff = lane * 16;
+    const int q16 = lane >> 4, r16 = lane & 15;
+    const int lo16 = (q16 & 1) * SLOT + ((q16 >> 1) * 32 + r16) * 16;      // (+ 256: the upper 16 rows of a 32-wide tile)
     const int pair = xb * XPW + xp;
     const bool active = pair < npair;
     const int tile0 = (active ? pair : npair - 1) * 2;    // a wave without a pair streams the last one again (it still feeds the ring)
 
-    const long long ks0 = (long long)split * steps_per_split;
+    const long long ks0 = (long long)split * steps_per_split + 2 * s_lo;
     const unsigned ybytes = (unsigned)(steps_per_split + PIPE_D) * 1024u;
     const unsigned fbytes = (unsigned)(steps_per_split + PIPE_D) * (NF * 1024u);
     __amdgpu_buffer_rsrc_t yr[NYD];
@@ -495,7 +511,6 @@ __global__ __launch_bounds__(512) void stream_lds8_kernel(const uint4* __restric
     for (int i = 0; i < NYD; ++i)
         yr[i] = __builtin_amdgcn_make_buffer_rsrc((void*)(Yt + (((long long)(tile0 + (HS == 2 ? hs : i))) * KS + ks0) * 64), 0, ybytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc((void*)(Ft + ks0 * (NF * 64) + wib * (NFD * 64)), 0, fbytes, 0x00020000);
-    const int voff = lane * 16;
     // this wave's pieces of k-step `step` into slot `slot`
     auto dma_step = [&](int step, int slot) __attribute__((always_inline)) {
         unsigned char* base = smem + slot * SLOT;
@@ -518,10 +533,6 @@ __global__ __launch_bounds__(512) void stream_lds8_kernel(const uint4* __restric
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b) acq[i][h][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int q16 = lane >> 4, r16 = lane & 15;
-    const int lo16 = (q16 & 1) * SLOT + ((q16 >> 1) * 32 + r16) * 16;      // (+ 256: the upper 16 rows of a 32-wide tile)
-
-    const int nst = steps_per_split >> 1;      // stages of two k-steps (the host pads k-steps to an even count)
     dma_step(0, 0); dma_step(1, 1); dma_step(2, 2); dma_step(3, 3);
 
     for (int st0 = 0; st0 < nst; st0 += 3) {
@@ -593,13 +604,13 @@ __global__ __launch_bounds__(512) void stream_lds8_kernel(const uint4* __restric
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // run-ahead pieces (slack of the tiled buffers) still target this LDS
-    if (!active) return;
+    if (active) {
     // 16 x 16 tile (hi, xi): lane (q, c) holds column x = 16 xi + c, rows h = 16 hi + 4 q + t in register t.  The 32 x 32 tile
     // wants lane (half, c') = column c', register r = 4 g + t <-> row (r & 3) + 8 (r >> 2) + 4 half, i.e. half = q & 1,
     // g = 2 hi + (q >> 1).  With S0, S1 = register t of sub-tiles xi = 0, 1 as rows of 16 lanes [r0 r1 r2 r3]:
     // v_permlane16_swap -> [S0.r0 S1.r0 S0.r2 S1.r2], [S0.r1 S1.r1 S0.r3 S1.r3]; v_permlane32_swap of those two ->
     // [S0.r0 S1.r0 S0.r1 S1.r1] = register 4 (2 hi) + t and [S0.r2 S1.r2 S0.r3 S1.r3] = register 4 (2 hi + 1) + t.
-    float* o = Out + (long long)split * (NH * 32) * ldOut;
+    float* o = Out + (long long)(SK ? slab : split) * (NH * 32) * ldOut;
     float4* o4 = reinterpret_cast<float4*>(o);
     const int c = lane & 31, half = lane >> 5;
 #pragma unroll
@@ -627,6 +638,28 @@ __global__ __launch_bounds__(512) void stream_lds8_kernel(const uint4* __restric
                 for (int r = 0; r < 16; ++r) o[(long long)((hs * 4 + h) * 32 + rho(r, half)) * ldOut + x] = a[r];
             }
         }
+    }                                                     // active
+}
+
+// Fix-up of a segment-list launch: Out[block] += sum_{t = 1 .. nslab-1} slab_t[block] for the blocks that were cut (list: block
+// indices; block_floats contiguous floats per block in the fragment-major product; slab stride = total_floats).  Fixed order.
+__global__ __launch_bounds__(256) void streamk_fixup_kernel(float* __restrict__ Out, int nslab, const int* __restrict__ list, int nlist,
+                                                            long long block_floats, long long total_floats,
+                                                            const int* __restrict__ stop) {
+    if (stop && *stop) return;
+    const long long n4 = block_floats >> 2;
+    for (int b = blockIdx.y; b < nlist; b += gridDim.y) {
+        const long long base = (long long)list[b] * block_floats;
+        float4* o = reinterpret_cast<float4*>(Out + base);
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4 && base + 4 * i < total_floats; i += (long long)gridDim.x * 256) {
+            float4 a = o[i];
+            for (int t = 1; t < nslab; ++t) {
+                const float4 b2 = reinterpret_cast<const float4*>(Out + (long long)t * total_floats + base)[i];
+                a.x += b2.x; a.y += b2.y; a.z += b2.z; a.w += b2.w;
+            }
+            o[i] = a;
+        }
+    }
 }
 
 }  // namespace vbmf

@@ -111,6 +111,11 @@ struct vbmf_ctx {
     int gslab_cap = 256;
     size_t gslab_bytes = 0;           // allocated size of gslab: every Gram launcher checks its slab count against it
     bool xcd_map = true;              // XCD-aware work map for split-K pass launches (env VBMF_XCD_MAP=0 turns it off)
+    // stream-K split of the un-split Y*A pass on the LDS-DMA kernel (stream_gemm.hpp): units per workgroup (0: off), workgroups,
+    // the blocks that end up in two parts (device list) and the second slab they go to (c->Q + one slab)
+    int sk_per = 0, sk_grid = 0, sk_ntail = 0;      // sk_per: pieces per cut block (T; 0: off); sk_grid: segments = workgroups
+    int* sk_tail = nullptr;                          // the cut blocks (device list)
+    int* sk_list = nullptr;                          // the segment list: int4 (block, first stage, stages, slab) per workgroup
     bool lds8 = true;                 // H >= 128, bf16x2 operands: the 512-thread LDS-DMA streaming kernel (env VBMF_LDS8=0: the per-wave kernel,
                                       // kept for A/B runs and for the fp32 / single-bf16 operand modes)
     bool P_frag = false;              // the Y'B product in c->P / c->Pred is fragment-major (stream_gemm.hpp, frag_out)
@@ -386,14 +391,23 @@ static int launch_stream(vbmf_ctx* c, int pass, int ctrl_mode = 0, bool epi = fa
     prof_begin(c, pass);
     if (use_lds8(c) && !epi) {
         if (lds > (size_t)LDS8_BYTES) FAIL(c, VBMF_ERR_INVALID, "internal: control chain needs %zu bytes of LDS", lds);
-        // same workgroup footprint as the per-wave kernel (8 x tiles at H = 256, 16 at H = 128): grid, split-K plan and the
-        // XCD-aware map carry over unchanged
-        if (c->NH == 4) {
-            hipLaunchKernelGGL((stream_lds8_kernel<4, StreamCfg<4>::Rc>), dim3(grid), dim3(512), LDS8_BYTES, c->stream, Y, F, out, d.XT, d.KS,
-                               d.steps_per_split, d.nsplit, ld, c->ints + I_STOP, ca, xper, ea.frag_out);
-        } else {
-            hipLaunchKernelGGL((stream_lds8_kernel<8, 0>), dim3(grid), dim3(512), LDS8_BYTES, c->stream, Y, F, out, d.XT, d.KS,
-                               d.steps_per_split, d.nsplit, ld, c->ints + I_STOP, ca, xper, ea.frag_out);
+        // stream-K: the fragment-major product of the un-split Y*A pass, balanced over the chip (plan: vbmf_create)
+        const bool sk = pass == 1 && frag_out && c->sk_per > 0 && d.nsplit == 1;
+        const int sk_per = sk ? c->sk_grid : 0;                                   // (the kernel's argument: number of segments)
+        const float* out2 = sk ? reinterpret_cast<const float*>(c->sk_list) : nullptr;   // ... and the segment list
+        const int grid8 = sk ? c->sk_grid + (ctrl_mode ? 2 : 0) : grid;
+        const int xper8 = sk ? 0 : xper;
+#define LDS8_LAUNCH(NHc_, Rc_, SKc_)                                                                                                     \
+    hipLaunchKernelGGL((stream_lds8_kernel<NHc_, Rc_, SKc_>), dim3(grid8), dim3(512), LDS8_BYTES, c->stream, Y, F, out, d.XT, d.KS,   \
+                       d.steps_per_split, d.nsplit, ld, c->ints + I_STOP, ca, xper8, ea.frag_out, sk_per, out2)
+        if (c->NH == 4) { if (sk) LDS8_LAUNCH(4, StreamCfg<4>::Rc, true); else LDS8_LAUNCH(4, StreamCfg<4>::Rc, false); }
+        else { if (sk) LDS8_LAUNCH(8, 0, true); else LDS8_LAUNCH(8, 0, false); }
+#undef LDS8_LAUNCH
+        if (sk && c->sk_ntail > 0) {
+            // the blocks that were cut: product += its second part (a block is contiguous in the fragment-major layout)
+            const long long blk = (long long)(c->NH == 8 ? 8 : 16) * c->NH * 1024;        // x tiles per workgroup * NH tiles * 1024 floats
+            hipLaunchKernelGGL(streamk_fixup_kernel, dim3(16, std::min(c->sk_ntail, 1024)), dim3(256), 0, c->stream, out, c->sk_per, c->sk_tail,
+                               c->sk_ntail, blk, (long long)c->Hp * c->Lp, c->ints + I_STOP);
         }
     } else if (epi) {
         DISPATCH_MODE(c->mode, {
@@ -1041,7 +1055,7 @@ int vbmf_destroy(vbmf_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     prof_harvest(c);
     if (c->comm) ncclCommDestroy(c->comm);
-    void* bufs[] = {c->gw, c->hmean, c->fws, c->t2part, c->Y1, c->Y2, c->FA_alloc, c->FB_alloc, c->FD, c->SBf, c->P, c->Q, c->Pred, c->A32, c->B32[0], c->B32[1], c->SA32,
+    void* bufs[] = {c->sk_list, c->sk_tail, c->gw, c->hmean, c->fws, c->t2part, c->Y1, c->Y2, c->FA_alloc, c->FB_alloc, c->FD, c->SBf, c->P, c->Q, c->Pred, c->A32, c->B32[0], c->B32[1], c->SA32,
                     c->SB32, c->gslab, c->st, c->gtmp, c->ypart, c->trpart, c->ints, c->mask, c->dS32, c->CA32, c->beta32, c->vtab,
                     c->sigv, c->zetav, c->yrow, c->hpart, c->vsq, c->sig32, c->G32, c->FBs_alloc, c->gpart, c->fpart};
     for (void* b : bufs) if (b) hipFree(b);
@@ -1170,7 +1184,45 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
     c->FB = c->FB_alloc + flead;
     c->FA = c->FA_alloc + flead;
     ALLOC(c->P, (size_t)c->d1.nsplit * c->Hp * c->Mp * 4);
-    ALLOC(c->Q, (size_t)c->d2.nsplit * c->Hp * c->Lp * 4);
+    {   // Segment-list plan of the Y*A pass (LDS-DMA kernel, un-split, the last round of workgroups mostly empty): whole blocks
+        // for the full rounds, then the R remaining blocks cut T ways in k, pieces k-major (stream_gemm.hpp, SK)
+        const char* ev = getenv("VBMF_STREAMK");
+        const int xpw = c->NH == 8 ? 8 : 16;                                   // x tiles per workgroup of stream_lds8_kernel
+        const int bps2 = cdiv(c->d2.XT, xpw), nst = c->d2.steps_per_split / 2;
+        const int nfull = bps2 / NUM_CU * NUM_CU, R = bps2 - nfull;
+        // OFF unless VBMF_STREAMK=1 -- measured, not faster (profiles/r03_g_segment_list_ab.txt): config 5's Y*A pass 0.80 ms + a
+        // 0.04 ms fix-up against 0.83 ms for the plain two rounds (391 blocks on 254 CUs, nominally 77 % efficient).  These passes run at
+        // the chip's power limit: while the second round keeps only 137 CUs busy the clock rises, so the schedule's idle CUs cost far
+        // less than their count says -- the time is set by the MFMA work, not by how it is dealt.  (An earlier cut at arbitrary stages,
+        // every workgroup at its own k, was 25 % SLOWER: the factor then comes from beyond L2.)  Kept as a tested switch.
+        if (use_lds8(c) && c->d2.nsplit == 1 && nfull > 0 && R > 0 && (double)R / NUM_CU < 0.8 && (ev && atoi(ev) == 1)) {
+            int bestT = 0;
+            double best = 0.93;                                                // time of the last round, in whole-block times (1.0 un-cut)
+            for (int T : {2, 3, 4, 5}) {
+                if (nst / T < 6) break;                                        // a piece keeps >= 6 stages (pipeline fill / drain per piece)
+                const double t = (double)cdiv((int64_t)R * T, NUM_CU) / T;
+                if (t < best - 1e-9) { best = t; bestT = T; }
+            }
+            if (bestT > 0) {
+                std::vector<int> seg, tails;
+                for (int b = 0; b < nfull; ++b) { seg.push_back(b); seg.push_back(0); seg.push_back(nst); seg.push_back(0); }
+                for (int t = 0; t < bestT; ++t)
+                    for (int b = nfull; b < bps2; ++b) {
+                        const int s0 = (int)((int64_t)nst * t / bestT), s1 = (int)((int64_t)nst * (t + 1) / bestT);
+                        seg.push_back(b); seg.push_back(s0); seg.push_back(s1 - s0); seg.push_back(t);
+                    }
+                for (int b = nfull; b < bps2; ++b) tails.push_back(b);
+                c->sk_per = bestT; c->sk_grid = (int)(seg.size() / 4); c->sk_ntail = (int)tails.size();
+                ALLOC(c->sk_list, seg.size() * sizeof(int));
+                ALLOC(c->sk_tail, tails.size() * sizeof(int));
+                if (hipMemcpy(c->sk_list, seg.data(), seg.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+                    hipMemcpy(c->sk_tail, tails.data(), tails.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+                    c->err = "segment-list plan upload failed"; return bail(VBMF_ERR_HIP);
+                }
+            }
+        }
+    }
+    ALLOC(c->Q, (size_t)(c->sk_per > 0 ? c->sk_per : c->d2.nsplit) * c->Hp * c->Lp * 4);
     ALLOC(c->Pred, (size_t)c->Hp * c->Mp * 4);
     ALLOC(c->A32, (size_t)c->Mp * c->Hp * 4);
     ALLOC(c->B32[0], (size_t)c->Lp * c->Hp * 4);
@@ -1244,9 +1296,13 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
             });
         }
         if (e == hipSuccess && c->NH == 4)
-            e = hipFuncSetAttribute((const void*)stream_lds8_kernel<4, StreamCfg<4>::Rc>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8_BYTES);
+            e = hipFuncSetAttribute((const void*)stream_lds8_kernel<4, StreamCfg<4>::Rc, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8_BYTES);
+        if (e == hipSuccess && c->NH == 4)
+            e = hipFuncSetAttribute((const void*)stream_lds8_kernel<4, StreamCfg<4>::Rc, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8_BYTES);
         if (e == hipSuccess && c->NH == 8)
-            e = hipFuncSetAttribute((const void*)stream_lds8_kernel<8, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8_BYTES);
+            e = hipFuncSetAttribute((const void*)stream_lds8_kernel<8, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8_BYTES);
+        if (e == hipSuccess && c->NH == 8)
+            e = hipFuncSetAttribute((const void*)stream_lds8_kernel<8, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8_BYTES);
         if (e != hipSuccess) { c->err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"; return bail(VBMF_ERR_HIP); }
     }
     // the zero-fills above ran on the null stream; all later work runs on a non-blocking stream
@@ -1865,7 +1921,7 @@ int vbmf_debug_peek(vbmf_ctx* c, int what, uint32_t* out, int64_t nwords, int64_
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (what == VBMF_PEEK_DIMS) {
         const int v[16] = {c->Hp, c->NH, c->mode, c->d1.XT, c->d1.KS, c->d1.nsplit, c->d1.steps_per_split,
-                           c->d2.XT, c->d2.KS, c->d2.nsplit, c->d2.steps_per_split, c->kstep, c->npart, c->narrow ? 1 : 0, 0, 0};
+                           c->d2.XT, c->d2.KS, c->d2.nsplit, c->d2.steps_per_split, c->kstep, c->npart, c->narrow ? 1 : 0, c->sk_per, c->sk_grid};
         memcpy(out, v, sizeof(int) * (size_t)std::min<int64_t>(16, nwords));
         return VBMF_OK;
     }
