@@ -83,18 +83,33 @@ struct PivAcc {
 };
 
 // In-wave symmetric sweep of the 16 x 16 block held in the C/D layout: a <- -inv(a).  One step of the sweep operator per
-// pivot k, fully unrolled: row k comes from the lanes of 16-lane row k & 3 (register k >> 2) by a permlane broadcast, column
-// k from lane position k of each row by DPP.
+// pivot k, fully unrolled.  Pivot k needs column k at the lane's rows (lane position k of each 16-lane row: DPP row_newbcast) and
+// row k at the lane's column, which lives in 16-lane row k & 3, register k >> 2 -- a cross-row broadcast (ds_bpermute).
 // The step is ONE fma per element, a_ij <- a_ij - v_i w_j with v = column k, w = row k / d, the sweep's special cases (row k,
 // column k, the corner) obtained EXACTLY by patching the operands instead of selecting among three results per element:
 //     column-k lanes:  w := -1/d, a := 0     =>  -v_i (-1/d) = v_i / d
 //     row-k lanes:     v := -1,   a := 0     =>  w_j = u_j / d          (corner: both patches => -1/d)
 // (A variant that kept a and patched v := d - 1, w := 1 - 1/d is algebraically the same and one select cheaper per register --
 //  and cancels catastrophically once an ARD precision reaches 1e10: found by the two-group model's H0 = H test.)
+// "a := 0" clears the HIGH dword only: what is left is a denormal below 2^-1042, which the fma's rounding absorbs (one
+// v_cndmask instead of two).
+// The cross-row broadcast is taken off the critical path: row k+1 is fetched from the block BEFORE step k updates it (issued
+// first, waited for last) and brought up to date with the step's own w:  u_{k+1} <- u_{k+1} - A[k+1][k] w  (column k: the
+// patched form again).  What remains between two pivots is DPP(d) -> rcp -> w -> fma.
+__device__ __forceinline__ double zero_if(bool z, double x) {          // z ? (effectively) 0 : x
+    return __hiloint2double(z ? 0 : __double2hiint(x), __double2loint(x));
+}
+__device__ __forceinline__ double bperm_f64(int addr, double v) {
+    const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
 template <int KK>
-__device__ __forceinline__ void sweep16_step(f64x4& a, int c, int q, PivAcc& pv) {
+__device__ __forceinline__ void sweep16_step(f64x4& a, double& u, int c, int q, const int (&rowaddr)[4], PivAcc& pv) {
     constexpr int Q0 = KK & 3, R0 = KK >> 2;
-    const double u = rows_bcast<Q0>(a[R0]);                      // A[k][c]
+    constexpr int Q1 = (KK + 1) & 3, R1 = ((KK + 1) >> 2) & 3;
+    double un = 0.0;
+    if constexpr (KK < 15) un = bperm_f64(rowaddr[Q1], a[R1]);   // row k+1 as it stands BEFORE this step: A[k+1][c]
     double v[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = row_bcast16<KK>(a[r]);    // A[q + 4r][k]
@@ -105,17 +120,22 @@ __device__ __forceinline__ void sweep16_step(f64x4& a, int c, int q, PivAcc& pv)
     const double w = is_col ? -dinv : u * dinv;
     v[R0] = is_row ? -1.0 : v[R0];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const bool zero = is_col || (r == R0 && is_row);
-        a[r] = fma(-v[r], w, zero ? 0.0 : a[r]);
+    for (int r = 0; r < 4; ++r) a[r] = fma(-v[r], w, zero_if(is_col || (r == R0 && is_row), a[r]));
+    if constexpr (KK < 15) {
+        const double vk1 = row_bcast16<KK>(un);                  // A[k+1][k] before the step
+        u = fma(-vk1, w, zero_if(is_col, un));                   // row k+1 after it
     }
 }
 __device__ __forceinline__ void sweep16(f64x4& a, int lane, PivAcc& pv) {
     const int c = lane & 15, q = lane >> 4;
-    sweep16_step<0>(a, c, q, pv);  sweep16_step<1>(a, c, q, pv);  sweep16_step<2>(a, c, q, pv);  sweep16_step<3>(a, c, q, pv);
-    sweep16_step<4>(a, c, q, pv);  sweep16_step<5>(a, c, q, pv);  sweep16_step<6>(a, c, q, pv);  sweep16_step<7>(a, c, q, pv);
-    sweep16_step<8>(a, c, q, pv);  sweep16_step<9>(a, c, q, pv);  sweep16_step<10>(a, c, q, pv); sweep16_step<11>(a, c, q, pv);
-    sweep16_step<12>(a, c, q, pv); sweep16_step<13>(a, c, q, pv); sweep16_step<14>(a, c, q, pv); sweep16_step<15>(a, c, q, pv);
+    const int rowaddr[4] = {4 * c, 4 * (16 + c), 4 * (32 + c), 4 * (48 + c)};      // ds_bpermute byte addresses of lane (c, row Q)
+    double u = bperm_f64(rowaddr[0], a[0]);                      // row 0
+    sweep16_step<0>(a, u, c, q, rowaddr, pv);  sweep16_step<1>(a, u, c, q, rowaddr, pv);  sweep16_step<2>(a, u, c, q, rowaddr, pv);
+    sweep16_step<3>(a, u, c, q, rowaddr, pv);  sweep16_step<4>(a, u, c, q, rowaddr, pv);  sweep16_step<5>(a, u, c, q, rowaddr, pv);
+    sweep16_step<6>(a, u, c, q, rowaddr, pv);  sweep16_step<7>(a, u, c, q, rowaddr, pv);  sweep16_step<8>(a, u, c, q, rowaddr, pv);
+    sweep16_step<9>(a, u, c, q, rowaddr, pv);  sweep16_step<10>(a, u, c, q, rowaddr, pv); sweep16_step<11>(a, u, c, q, rowaddr, pv);
+    sweep16_step<12>(a, u, c, q, rowaddr, pv); sweep16_step<13>(a, u, c, q, rowaddr, pv); sweep16_step<14>(a, u, c, q, rowaddr, pv);
+    sweep16_step<15>(a, u, c, q, rowaddr, pv);
     pv.fold();
 }
 

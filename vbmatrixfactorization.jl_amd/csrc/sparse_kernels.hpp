@@ -223,7 +223,26 @@ __global__ __launch_bounds__(NW * 64) void sparse_update_a_full_wave_kernel(cons
             }
     }
     int bad = 0;
-    for (long long m = (long long)blockIdx.x * NW + w; m < M; m += (long long)gridDim.x * NW) {
+    // the column's own inputs -- CA[m, :] (one value per lane and diagonal block) and (B'Y)[:, m] (one per lane) -- are requested one
+    // column AHEAD: both are dependent trips to global memory (~2 us each) that would otherwise sit in front of every sweep
+    const long long mstep = (long long)gridDim.x * NW;
+    double ca_n[NBK], p_n = 0.0;
+    auto fetch = [&](long long m) __attribute__((always_inline)) {
+#pragma unroll
+        for (int I = 0; I < NBK; ++I) {
+            const int i = 16 * I + c16;
+            ca_n[I] = (m < M && i < H) ? (double)CA32[m * Hp + i] : 0.0;
+        }
+        p_n = (m < M && lane < H) ? (double)P[(long long)lane * ldP + m] : 0.0;
+    };
+    long long m = (long long)blockIdx.x * NW + w;
+    fetch(m);
+    for (; m < M; m += mstep) {
+        double ca_c[NBK];
+#pragma unroll
+        for (int I = 0; I < NBK; ++I) ca_c[I] = ca_n[I];
+        const double p_c = p_n;
+        fetch(m + mstep);
         {   // K_m = k0 + diag(CA[m,:]) into the image (upper blocks; the diagonal element of row 16 I + c sits in lane row c & 3, register c >> 2)
             int u = 0;
 #pragma unroll
@@ -232,27 +251,33 @@ __global__ __launch_bounds__(NW * 64) void sparse_update_a_full_wave_kernel(cons
                 for (int J = I; J < NBK; ++J, ++u) {
                     f64x4 x = k0[u];
                     if (I == J) {
-                        const int i = 16 * I + c16;
-                        const double ca = i < H ? (double)CA32[m * Hp + i] : 0.0;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) x[r] += (q16 == (c16 & 3) && r == (c16 >> 2)) ? ca : 0.0;
+                        for (int r = 0; r < 4; ++r) x[r] += (q16 == (c16 & 3) && r == (c16 >> 2)) ? ca_c[I] : 0.0;
                     }
                     if (I < nbu && J < nbu) blk_st_rows(W, LD, I, J, lane, x);
                 }
         }
-        for (int h = lane; h < NP; h += 64) pvec[h] = h < H ? (double)P[(long long)h * ldP + m] : 0.0;
+        if (lane < NP) pvec[lane] = p_c;                                // (H <= 64 = lanes: one value per lane; zero beyond H)
         PivAcc pv;
         blk_sweep<NBK, 1>(W, LD, nbu, 0, lane, pv);                     // W's upper blocks = -Sigma_m
         bad |= pv.bad;
-        // vec(A')[m,:] = msc Sigma_m (B'Y)[:, m]: lane i takes row i of the symmetric matrix (upper storage)
-        for (int i = lane; i < H; i += 64) {
+        // vec(A')[m,:] = msc Sigma_m (B'Y)[:, m]: lane i takes row i of the symmetric matrix (upper storage); a loop of fixed
+        // length with the triangle chosen per element, so that the reads pipeline (bounds that depend on the lane do not)
+        {
+            const int i = lane < H ? lane : 0;
             double sm = 0.0;
-            for (int j = 0; j < i; ++j) sm += W[j * LD + i] * pvec[j];
-            for (int j = i; j < H; ++j) sm += W[i * LD + j] * pvec[j];
-            float av = (float)(-msc * sm);
-            if (mask != nullptr && i >= hmask_start && mask[m]) av = 0.f;
-            A32[m * Hp + i] = av;
-            dS32[m * Hp + i] = (float)(-W[i * LD + i]);
+            const int nj = 16 * nbu;                                    // (blocks beyond nbu were never written)
+#pragma unroll 8
+            for (int j = 0; j < nj; ++j) {
+                const int lo = j < i ? j : i, hi = j < i ? i : j;
+                sm += W[lo * LD + hi] * pvec[j];                        // (pvec is zero beyond H; W is the identity padding there)
+            }
+            if (lane < H) {
+                float av = (float)(-msc * sm);
+                if (mask != nullptr && lane >= hmask_start && mask[m]) av = 0.f;
+                A32[m * Hp + lane] = av;
+                dS32[m * Hp + lane] = (float)(-W[lane * LD + lane]);
+            }
         }
         {
             int u = 0;
