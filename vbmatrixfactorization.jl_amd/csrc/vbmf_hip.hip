@@ -260,7 +260,7 @@ constexpr int NUM_CU = 254;
 #endif
 
 static void plan_pass(Dims& d, int64_t X, int64_t K, int kstep, int NH, int Hp, double ybytes, int want_splits, bool narrow,
-                      int kq_also = 0) {
+                      int kq_also = 0, bool two_rounds_at_nh8 = true) {
     // padding quanta: x tiles to the per-wave tile count, k-steps to the Y ring depth (zero tiles are streamed
     // like real ones, so padding is pure waste: 3.7 % of pass 2 at 100k x 10k with the old 8-tile / 12-step quanta)
     const int xq = nxw_of(NH, narrow), kq = std::max(dy_of(NH, narrow), kq_also);
@@ -292,7 +292,9 @@ static void plan_pass(Dims& d, int64_t X, int64_t K, int kstep, int NH, int Hp, 
     // H > 128: the stand-alone control kernels run beside the passes on a side stream and hold a CU each for
     // 0.3-0.5 ms; a one-round pass then ends that much later (its last workgroup waits for the busy CU), a two-round
     // pass of half-size workgroups just gives that CU fewer of them (measured at 100k x 10k, H = 256: 1.13 -> 0.83 ms)
-    if (want_splits <= 0 && NH == 8 && bps * ns <= NUM_CU && 2 * ns <= ks_min / (2 * kq)) ns *= 2;
+    // (round 3: not with the 512-thread LDS-DMA kernel -- one round of whole-size workgroups is as fast there, and half the slices
+    //  are half the partial slabs to write and to sum: config 5 +1.3 %, profiles/r03_h_cfg5_splits.txt)
+    if (want_splits <= 0 && NH == 8 && two_rounds_at_nh8 && bps * ns <= NUM_CU && 2 * ns <= ks_min / (2 * kq)) ns *= 2;
     ns = (int)std::max<int64_t>(1, std::min<int64_t>(ns, std::max<int64_t>(1, ks_min / kq)));
     d.nsplit = ns;
     d.steps_per_split = (int)rup(cdiv(ks_min, d.nsplit), kq);
@@ -1151,7 +1153,7 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
         const int64_t groups = std::min(cdiv(M, wq), cdiv(Lnom, wq));
         c->narrow = c->NH <= 2 && (ev ? atoi(ev) != 0 : groups <= 2);
     }
-    plan_pass(c->d1, M, L, c->kstep, c->NH, c->Hp, ybytes, c->o.pass1_splits, c->narrow);
+    plan_pass(c->d1, M, L, c->kstep, c->NH, c->Hp, ybytes, c->o.pass1_splits, c->narrow, 0, !use_lds8(c));
     plan_pass(c->d2, L, M, c->kstep, c->NH, c->Hp, ybytes, 0, c->narrow, (c->NH == 2 && !c->narrow) ? VBMF_EPI_DY : 0);
     c->Mp = (int64_t)c->d1.XT * 32;
     c->Lp = (int64_t)c->d2.XT * 32;
