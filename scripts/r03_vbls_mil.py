@@ -46,11 +46,15 @@ def main():
         for f in ("AHat", "BHat", "SigmaA", "SigmaB", "CA", "CB", "invCA", "invCB"):
             setattr(resg, f, getattr(res, f).copy())
         pkg.vbls_(bags[0], pkg.copy_vbmf_params(bags[0], resg, rng=np.random.default_rng(1)), 150)      # warm the library
+        # the caller's pattern: one bag at a time, the previous one garbage by then (a session whose matrix died is re-used for the
+        # next matrix of its shape: __init__.py, _session_for)
         t0 = time.perf_counter()
         worst = 0.0
-        for Y in bags:
+        for i in range(nb):
+            Y = bags[i].copy()
             pg = pkg.copy_vbmf_params(Y, resg, rng=np.random.default_rng(1))
             pkg.vbls_(Y, pg, 150)
+            del Y
         t_gpu = (time.perf_counter() - t0) / nb
         po = O.copy_vbmf_params(bags[-1], res, rng=np.random.default_rng(1)); O.vbls_(bags[-1], po, 150)
         worst = float(np.linalg.norm(pg.AHat - po.AHat) / np.linalg.norm(po.AHat))

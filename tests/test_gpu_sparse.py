@@ -308,7 +308,9 @@ def test_full_cov_logged_trajectory_against_the_reference_record(pkg, golden_dir
     assert abs(p.zeta - 21.72598805535064) < 2e-3 * 21.7
 
 
-@pytest.mark.parametrize("L,M,H", [(300, 150, 6), (420, 60, 40), (400, 30, 100)])
+# (60 000 x 26, H = 128: the shape of the round-2 advisor's finding -- 1 876 row tiles, where the weighted Gram's chunking wrote 118
+#  slabs into a buffer sized for 94; the buffer is sized for every chunking now and every Gram launcher checks its slab count)
+@pytest.mark.parametrize("L,M,H", [(300, 150, 6), (420, 60, 40), (400, 30, 100), (60000, 26, 128)])
 def test_full_cov_with_heteroscedastic_rows(pkg, L, M, H):
     """full_cov = true WITH diag_var = true (src/vbmf_sparse.jl:180-182, 192-193): per-column blocks
     K_m = B' diag(sigmaVec) B + L mean(sigmaVec) SigmaB + diag(CA[m,:]) -- the weighted Gram is an extra reduction over the rows
@@ -327,7 +329,8 @@ def test_full_cov_with_heteroscedastic_rows(pkg, L, M, H):
     pg = _to_pkg_hetero(pkg, po)
     pkg.sparse_updateB_(Yf, pg, diag_var=True); O.sparse_updateB(Yf, po, diag_var=True)     # consumes the full SigmaA
     _cmp(f"full_cov+diag_var {L}x{M} H{H} updateB", pg, po, 5e-5, ("BHat", "SigmaB"))
-    if M * H <= 4000:
+    if M * H <= 4000 and L < 10000:      # (at 60 000 x 26 the model prunes every column within five sweeps -- A, B -> 0 in the oracle too:
+        #                                     a relative comparison of the factors is meaningless there; the single updates above are the test)
         pg = _to_pkg_hetero(pkg, po)
         d_gpu = pkg.vbmf_sparse_(Yf, pg, 5, eps=0.0, full_cov=True, diag_var=True)
         d_ref, _ = O.vbmf_sparse_(Yf, po, 5, eps=0.0, full_cov=True, diag_var=True)

@@ -77,6 +77,43 @@ def test_vbls_hxh_loop_against_the_general_path_and_the_oracle(pkg, monkeypatch,
     assert relF(a.AHat, b.AHat) < 2e-5 and relF(a.SigmaA, b.SigmaA) < 2e-3 and abs(a.sigma2 - b.sigma2) < 2e-3 * b.sigma2
 
 
+def test_sessions_of_dead_matrices_are_reused(pkg, monkeypatch):
+    """A caller that walks over many small matrices of one shape (the MIL classifier's bags) must not pay a context creation per
+    matrix: once a matrix is garbage, its session serves the next matrix of the same shape, rank and storage defaults -- with
+    the same results as a fresh session."""
+    import gc
+    L, M, M2, H = 230, 300, 60, 10
+    Y, _ = _train_and_new_bag(L, M, M2, H, 55)
+    pkg.set_defaults(y_dtype=pkg.VBMF_Y_F32, factor_dtype=pkg.VBMF_FACTOR_AUTO)
+    po = O.vbmf_init(Y, H, ca=0.1, cb=0.1, sigma2=0.1, rng=np.random.default_rng(25), materialize_yhat=False)
+    O.vbmf_(Y, po, 10, eps=0.0, est_covs=True, est_var=True)
+    rng = np.random.default_rng(3)
+    bags = [rng.standard_normal((L, M2)) for _ in range(4)]
+    pkg.invalidate()
+    created = []
+    real = pkg.Session.__init__
+
+    def counting(self, *a, **k):
+        created.append(a[:3])
+        real(self, *a, **k)
+    monkeypatch.setattr(pkg.Session, "__init__", counting)
+    outs = []
+    for b in bags:
+        Yb = b.copy()
+        qg = pkg.copy_vbmf_params(Yb, to_pkg_params(pkg, po), rng=np.random.default_rng(26))
+        pkg.vbls_(Yb, qg, 12)
+        outs.append(qg.AHat.copy())
+        del Yb, qg
+        gc.collect()
+    assert len(created) == 1, created                            # one context for the four bags
+    pkg.invalidate()
+    for b, a in zip(bags, outs):                                 # ... and the same numbers as a fresh session per bag
+        qg = pkg.copy_vbmf_params(b, to_pkg_params(pkg, po), rng=np.random.default_rng(26))
+        pkg.vbls_(b, qg, 12)
+        assert np.array_equal(qg.AHat, a)
+        pkg.invalidate()
+
+
 def test_vbls_sparse_device_loop(pkg):
     L, M, M2, H = 400, 260, 150, 5
     Y, Y2 = _train_and_new_bag(L, M, M2, H, 91)

@@ -189,6 +189,10 @@ _sessions = {}
 _FP_FULL, _FP_SAMPLE = 1 << 22, 1 << 16
 
 
+_POOL_ELEMS = 1 << 20      # sessions of matrices up to this many elements are pooled after their matrix died ...
+_POOL_MAX = 48             # ... at most this many
+
+
 def _fingerprint(Y):
     """Content fingerprint of the caller's matrix (whole matrix up to _FP_FULL elements, a strided sample beyond).  Compared as
     BYTES: the CRC of the sampled values, plus two sums kept as bit patterns so that a matrix holding NaN still equals itself
@@ -230,9 +234,25 @@ def _session_for(Y, H):
             ent[0].set_Y(Y)
             _sessions[key] = (ent[0], ent[1], fp)
         return ent[0]
-    for k in [k for k, v in _sessions.items() if v[1]() is None or k[:3] == key[:3]]:
+    # A session whose matrix has been garbage-collected is RE-USED for a new matrix of the same shape, rank and storage
+    # defaults (set_Y on the existing context: no allocation, no stream / event creation -- what a caller that walks over many
+    # small matrices of a few shapes pays per call otherwise; the MIL classifier's bags, examples/mil_util.jl:473-479).  Small
+    # problems only (a dead session of a large matrix holds gigabytes: closed at once), at most _POOL_MAX of them.
+    dead = [k for k, v in _sessions.items() if v[1]() is None or k[:3] == key[:3]]
+    s = None
+    for k in dead:
+        if s is None and k[0] != "noY" and k[1] == key[1] and k[3:] == key[3:] and Y.size <= _POOL_ELEMS:
+            s = _sessions.pop(k)[0]
+    keep = 0
+    for k in dead:
+        if k not in _sessions:
+            continue
+        if k[0] != "noY" and k[:3] != key[:3] and k[1][0] * k[1][1] <= _POOL_ELEMS and keep < _POOL_MAX:
+            keep += 1                           # stays pooled for a later matrix of its shape
+            continue
         _sessions.pop(k)[0].close()
-    s = Session(Y.shape[0], Y.shape[1], H)
+    if s is None:
+        s = Session(Y.shape[0], Y.shape[1], H)
     s.set_Y(Y)
     try:
         ref = weakref.ref(Y)
