@@ -59,6 +59,40 @@ def main():
         po = O.copy_vbmf_params(bags[-1], res, rng=np.random.default_rng(1)); O.vbls_(bags[-1], po, 150)
         worst = float(np.linalg.norm(pg.AHat - po.AHat) / np.linalg.norm(po.AHat))
         rows.append((f"vbls! x150, basic   L={L} M={M} H={H}", t_cpu, t_gpu, worst))
+        # --- ARD-sparse model, 20 iterations with full_cov = true (the 'dual' classifier, :518-521) ---
+        so = O.vbmf_sparse_init(Ytr, H, ca=1.0, cb=1.0, sigma=1.0, rng=np.random.default_rng(7), full_cov=False, materialize_yhat=False)
+        O.vbmf_sparse_(Ytr, so, 12, eps=0.0, full_cov=False)
+        nbf = max(2, nb // 4) if M * H > 1000 else nb            # the reference's own MH x MH inverse: seconds per call at M*H = 2000
+
+        def cpu_full(Y):
+            q = O.copy_vbmf_params(Y, so, rng=np.random.default_rng(1))
+            for _ in range(20):                                  # examples/mil_util.jl:186-189 with full_cov = true
+                O.sparse_updateA(Y, q, full_cov=True)
+                O.sparse_updateCA(q)
+                O.sparse_updateSigma(Y, q)
+            return q
+        t0 = time.perf_counter()
+        for Y in bags[:nbf]:
+            qo = cpu_full(Y)
+        t_cpu = (time.perf_counter() - t0) / nbf
+        sg = pkg.vbmf_sparse_parameters()
+        for f in ("L", "M", "H", "MH", "H1", "alpha0", "beta0", "alpha", "gamma0", "delta0", "gamma", "sigmaHat", "eta0", "zeta0",
+                  "eta", "zeta", "trYTY"):
+            setattr(sg, f, getattr(so, f))
+        sg.labels = np.asarray(so.labels, dtype=np.int64) + 1
+        for f in ("AHat", "ATVecHat", "diagSigmaATVec", "SigmaA", "BHat", "SigmaB", "CA", "beta", "CB", "delta"):
+            setattr(sg, f, getattr(so, f).copy())
+        pkg.vbls_(bags[0], pkg.copy_vbmf_params(bags[0], sg, rng=np.random.default_rng(1)), 20, full_cov=True)
+        t0 = time.perf_counter()
+        for i in range(nb):
+            Y = bags[i].copy()
+            qg = pkg.copy_vbmf_params(Y, sg, rng=np.random.default_rng(1))
+            pkg.vbls_(Y, qg, 20, full_cov=True)
+            del Y
+        t_gpu = (time.perf_counter() - t0) / nb
+        qo = cpu_full(bags[-1])
+        worst = float(np.linalg.norm(qg.AHat - qo.AHat) / np.linalg.norm(qo.AHat))
+        rows.append((f"vbls! x20, sparse full_cov L={L} M={M} H={H}", t_cpu, t_gpu, worst))
     print(f"{'call':46s} {'oracle (host) ms':>18s} {'device ms':>12s} {'ratio':>8s} {'rel.err AHat':>14s}")
     for name, tc, tg, w in rows:
         print(f"{name:46s} {tc * 1e3:18.3f} {tg * 1e3:12.3f} {tc / tg:8.2f} {w:14.2e}")
