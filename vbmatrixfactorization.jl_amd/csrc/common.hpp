@@ -96,4 +96,14 @@ struct Dims {               // one streaming pass: Out[h][x] = sum_k F[k][h] * Y
     int steps_per_split;    // KS / nsplit, multiple of the Y ring depth
 };
 
+// one 1 KiB LDS-DMA piece: 64 lanes x 16 bytes from (descriptor, lane * 16 + soff) to lds + lane * 16 (lds wave-uniform).
+// (Plain functions, not inside the kernel template: with the address-space cast in the template's lambda hipcc (ROCm 7.2)
+// silently drops the HOST-side instantiation of the kernel -- no diagnostic, the launch stub is simply missing at link time.)
+__device__ __forceinline__ void lds_dma_piece(__amdgpu_buffer_rsrc_t r, unsigned char* lds, int voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+}
+__device__ __forceinline__ void lds_dma_piece_nt(__amdgpu_buffer_rsrc_t r, unsigned char* lds, int voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 2);
+}
+
 }  // namespace vbmf

@@ -693,6 +693,108 @@ __global__ __launch_bounds__(256) void split_table_parts_kernel(const float* __r
 #endif
 template <int NH> struct PostFrag2Cfg { static constexpr int NXT = NH >= 8 ? VBMF_POST2_NXT8 : VBMF_POST2_NXT4; };
 
+// The tail of the H >= 128 factor update, shared by post_frag2_kernel and post_frag3_kernel: the wave's NXT x NH accumulator blocks
+// -> mask, operand tiles, delta tiles, fp32 factor, tr(B'YA) share.  `wslot` = this wave's slot in trpart ([4 * workgroups]).
+template <int MODE, int NH, int NXT, bool BSIDE>
+__device__ __forceinline__ void post_frag_tail(f32x16 (&acc)[NXT][NH], const float4* __restrict__ In4, float* __restrict__ Fac,
+                                               uint4* __restrict__ Ft, const unsigned char* __restrict__ mask, int hmask_start,
+                                               int XT, int xt0, double* __restrict__ trpart, uint4* __restrict__ Fd, int store_fac,
+                                               float* tbw, int wslot, int lane) {
+    constexpr int Hp = NH * 32;
+    // accumulator layout: lane (c = h' in tile, half), register r -> row x0 + rho(r, half)
+    // (the store addresses are derived from an opaque copy of the lane id: computed up front, as the optimiser would, the 16
+    //  blocks' row pointers live across the main loop and push its operand rings into scratch)
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int c = lane_e & 31, half = lane_e >> 5;
+    double tr = 0.0;
+    const bool want_tr = BSIDE && trpart != nullptr;
+    const bool want_old = BSIDE && Fd != nullptr;
+    constexpr int NPART = ModeTraits<MODE>::NPART;
+    constexpr int NB = NXT * NH;                             // 32 x 32 blocks of this wave, b = i * NH + h
+    // ONE block at a time, everything that needs its accumulator tile inside (mask, operand tiles, delta tiles, fp32 store,
+    // tr(B'YA) share): a tile that had to survive until a later loop is 16 more live registers per block.  What a block READS
+    // (its previous operand tiles for the delta, its product fragments again for the trace: L2-hot) is requested one block
+    // ahead, so the round trip overlaps the block before.
+    uint4 on[2 * NPART], oc[2 * NPART];
+    float4 qn[4], qc4[4];
+    auto request = [&](int b) __attribute__((always_inline)) {
+        const int i = b / NH, h = b % NH;
+        const int xt = xt0 + i < XT ? xt0 + i : XT - 1;
+        if (want_old) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int pa = 0; pa < NPART; ++pa) on[s * NPART + pa] = Ft[(((long long)(2 * xt + s) * NPART + pa) * NH + h) * 64 + lane_e];
+        }
+        if (want_tr) {
+            const float4* t4 = In4 + (((long long)xt * NH + h) * 64 + lane_e) * 4;
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) qn[qd] = t4[qd];
+        }
+    };
+    // (with half the accumulator registers or fewer, two or more waves run per SIMD and overlap each other's round trips: no
+    //  read-ahead there, it would cost the 32 registers that keep the wave under 128 VGPRs)
+    constexpr bool AHEAD = NXT * NH >= 16;
+    if constexpr (AHEAD) request(0);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int i = b / NH, h = b % NH;
+        const int xt = xt0 + i;
+        if (xt >= XT) break;
+        const long long x0 = (long long)xt * 32;
+        const int hcol = h * 32 + c;
+        if constexpr (!AHEAD) request(b);
+#pragma unroll
+        for (int u = 0; u < 2 * NPART; ++u) oc[u] = on[u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) qc4[u] = qn[u];
+        if constexpr (AHEAD) {
+            if (b + 1 < NB) request(b + 1);
+        }
+        // (the tile is taken out of the accumulation registers HERE: common.hpp, acc_read_tile)
+        f32x16 a;
+        acc_read_tile(acc[i][h], a);
+        if constexpr (!BSIDE) {
+            if (mask != nullptr && hcol >= hmask_start) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (mask[x0 + rho(r, half)]) a[r] = 0.f;
+            }
+        }
+        // Fd (B side): old - new of this block as delta tiles; the old block is what the operand tiles held (read above, before
+        // they are overwritten here).  store_fac = 0 (inside the run loops): no fp32 copy per sweep.
+        write_factor_tiles<MODE, NH>(Ft, a, xt, h, lane_e);
+        if (want_old) {
+            f32x16 oldv;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const unsigned hw[4] = {oc[s * NPART].x, oc[s * NPART].y, oc[s * NPART].z, oc[s * NPART].w};
+                unsigned lw[4] = {0u, 0u, 0u, 0u};
+                if constexpr (NPART == 2) { lw[0] = oc[s * NPART + 1].x; lw[1] = oc[s * NPART + 1].y; lw[2] = oc[s * NPART + 1].z; lw[3] = oc[s * NPART + 1].w; }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float f = bf2f((unsigned short)(hw[e >> 1] >> (16 * (e & 1))));
+                    if constexpr (NPART == 2) f += bf2f((unsigned short)(lw[e >> 1] >> (16 * (e & 1))));
+                    oldv[8 * s + e] = f;
+                }
+            }
+            write_delta_tiles<NH>(Fd, oldv, a, xt, h, lane_e);
+        }
+        if (store_fac) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Fac[(x0 + rho(r, half)) * Hp + hcol] = a[r];
+        }
+        if (want_tr) {
+            float q[16];
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) { q[4 * qd] = qc4[qd].x; q[4 * qd + 1] = qc4[qd].y; q[4 * qd + 2] = qc4[qd].z; q[4 * qd + 3] = qc4[qd].w; }
+            tr += (double)tile_dot_qb<true>(q, a, tbw, lane_e);
+        }
+    }
+    if (want_tr) store_wave_dot(tr, trpart + wslot, lane_e);
+}
+
 // NXT: 32-row tiles per wave (PostFrag2Cfg<NH>::NXT on a long side, 1 on a short one: more workgroups)
 template <int MODE, int NH, int NXT, int NT, bool BSIDE>
 __global__ __launch_bounds__(256) void post_frag2_kernel(const float4* __restrict__ In4, const uint4* __restrict__ Sf,
@@ -789,99 +891,121 @@ __global__ __launch_bounds__(256) void post_frag2_kernel(const float4* __restric
         }
     }
 
-    // accumulator layout: lane (c = h' in tile, half), register r -> row x0 + rho(r, half)
-    // (the store addresses are derived from an opaque copy of the lane id: computed up front, as the optimiser would, the 16
-    //  blocks' row pointers live across the main loop and push its operand rings into scratch)
-    int lane_e = lane;
-    asm volatile("" : "+v"(lane_e));
-    const int c = lane_e & 31, half = lane_e >> 5;
-    double tr = 0.0;
-    float* tbw = tbuf[wib];
-    const bool want_tr = BSIDE && trpart != nullptr;
-    const bool want_old = BSIDE && Fd != nullptr;
-    constexpr int NPART = ModeTraits<MODE>::NPART;
-    constexpr int NB = NXT * NH;                             // 32 x 32 blocks of this wave, b = i * NH + h
-    // ONE block at a time, everything that needs its accumulator tile inside (mask, operand tiles, delta tiles, fp32 store,
-    // tr(B'YA) share): a tile that had to survive until a later loop is 16 more live registers per block.  What a block READS
-    // (its previous operand tiles for the delta, its product fragments again for the trace: L2-hot) is requested one block
-    // ahead, so the round trip overlaps the block before.
-    uint4 on[2 * NPART], oc[2 * NPART];
-    float4 qn[4], qc4[4];
-    auto request = [&](int b) __attribute__((always_inline)) {
-        const int i = b / NH, h = b % NH;
+    post_frag_tail<MODE, NH, NXT, BSIDE>(acc, In4, Fac, Ft, mask, hmask_start, XT, xt0, trpart, Fd, store_fac, tbuf[wib],
+                                         blockIdx.x * 4 + wib, lane);
+}
+
+// ---- post_frag3: post_frag2 with the table shared through LDS (two waves per SIMD) ---------------------------------------
+// post_frag2 at 100k x 256 (profiles/r03_cfg5_timeline.txt: 140 us) is neither at its matrix-pipe time (768 MFMAs per row tile:
+// ~36 us on 1024 SIMDs) nor at its HBM time (~70 us: product in, operand + delta tiles out, previous tiles in): every wave pulls
+// the whole 384 KiB table through its own registers -- 3 buffer loads per 12 MFMAs, each ~50 cycles of issue during which the one
+// wave of the SIMD feeds no MFMA (the streaming kernel's finding, stream_gemm.hpp) -- and 256 accumulator registers leave one wave
+// per SIMD, so the tail (stores, delta tiles, trace) of one wave overlaps nobody's MFMAs.  Here a (hin, s2) STAGE of the table
+// (NH * NT KiB) is brought into LDS once per workgroup by LDS-DMA (each wave a quarter), double-buffered one stage ahead behind ONE
+// raw barrier per stage; the waves read their B operands with ds_read_b128 (lane-linear, conflict-free).  128 accumulator registers
+// per wave (NXT = 1 at NH = 8, 2 at NH = 4) -> two workgroups per CU.  Same products in the same order as post_frag2: bit-identical.
+template <int MODE, int NH, int NXT, int NT, bool BSIDE>
+__global__ __launch_bounds__(256, 2) void post_frag3_kernel(const float4* __restrict__ In4, const uint4* __restrict__ Sf,
+                                                            float* __restrict__ Fac, uint4* __restrict__ Ft,
+                                                            const unsigned char* __restrict__ mask, int hmask_start, int XT,
+                                                            const int* __restrict__ stop, double* __restrict__ trpart,
+                                                            uint4* __restrict__ Fd, int store_fac) {
+    static_assert(MODE != MODE_F32, "bf16 factor modes only");
+    constexpr int STAGE = NH * NT;                            // 1 KiB pieces of one (hin, s2) stage: [h][part]
+    constexpr int NSTG = 2 * NH;
+    constexpr int PPW = STAGE / 4;                            // pieces each wave fetches per stage
+    static_assert(STAGE % 4 == 0, "four waves share the fetch");
+    static_assert(2 * STAGE * 1024 >= 4 * 32 * TB_LD * 4, "the tail's per-wave transposition buffers alias the ring");
+    __shared__ __attribute__((aligned(16))) unsigned char ring[2 * STAGE * 1024];
+    if (stop && *stop) return;
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int xt0r = (blockIdx.x * 4 + wib) * NXT;
+    const bool active = xt0r < XT;                           // a wave without tiles still fetches its quarter and meets the barriers
+    const int xt0 = active ? xt0r : XT - 1;
+    const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc((void*)Sf, 0, (unsigned)(NSTG * STAGE) * 1024u, 0x00020000);
+    __amdgpu_buffer_rsrc_t qrs[NXT];
+#pragma unroll
+    for (int i = 0; i < NXT; ++i) {
         const int xt = xt0 + i < XT ? xt0 + i : XT - 1;
-        if (want_old) {
+        qrs[i] = __builtin_amdgcn_make_buffer_rsrc((void*)(In4 + (long long)xt * NH * 256), 0, (unsigned)NH * 4096u, 0x00020000);
+    }
+    const int tvo = lane * 16, qvo = lane * 64;
+    auto dma_stage = [&](int st, int slot) __attribute__((always_inline)) {
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int pa = 0; pa < NPART; ++pa) on[s * NPART + pa] = Ft[(((long long)(2 * xt + s) * NPART + pa) * NH + h) * 64 + lane_e];
-        }
-        if (want_tr) {
-            const float4* t4 = In4 + (((long long)xt * NH + h) * 64 + lane_e) * 4;
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) qn[qd] = t4[qd];
-        }
+        for (int q = 0; q < PPW; ++q)
+            lds_dma_piece(trs, ring + (slot * STAGE + wib * PPW + q) * 1024, tvo, (st * STAGE + wib * PPW + q) * 1024);
     };
-    // (with half the accumulator registers or fewer, two or more waves run per SIMD and overlap each other's round trips: no
-    //  read-ahead there, it would cost the 32 registers that keep the wave under 128 VGPRs)
-    constexpr bool AHEAD = NXT * NH >= 16;
-    if constexpr (AHEAD) request(0);
+
+    f32x16 acc[NXT][NH];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        const int i = b / NH, h = b % NH;
-        const int xt = xt0 + i;
-        if (xt >= XT) break;
-        const long long x0 = (long long)xt * 32;
-        const int hcol = h * 32 + c;
-        if constexpr (!AHEAD) request(b);
+    for (int i = 0; i < NXT; ++i)
 #pragma unroll
-        for (int u = 0; u < 2 * NPART; ++u) oc[u] = on[u];
+        for (int h = 0; h < NH; ++h)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) qc4[u] = qn[u];
-        if constexpr (AHEAD) {
-            if (b + 1 < NB) request(b + 1);
-        }
-        // (the tile is taken out of the accumulation registers HERE: common.hpp, acc_read_tile)
-        f32x16 a;
-        acc_read_tile(acc[i][h], a);
-        if constexpr (!BSIDE) {
-            if (mask != nullptr && hcol >= hmask_start) {
+            for (int r = 0; r < 16; ++r) acc[i][h][r] = 0.f;
+
+    dma_stage(0, 0);
+    u32x4v qc[NXT][4];
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (mask[x0 + rho(r, half)]) a[r] = 0.f;
-            }
-        }
-        // Fd (B side): old - new of this block as delta tiles; the old block is what the operand tiles held (read above, before
-        // they are overwritten here).  store_fac = 0 (inside the run loops): no fp32 copy per sweep.
-        write_factor_tiles<MODE, NH>(Ft, a, xt, h, lane_e);
-        if (want_old) {
-            f32x16 oldv;
+    for (int i = 0; i < NXT; ++i)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const unsigned hw[4] = {oc[s * NPART].x, oc[s * NPART].y, oc[s * NPART].z, oc[s * NPART].w};
-                unsigned lw[4] = {0u, 0u, 0u, 0u};
-                if constexpr (NPART == 2) { lw[0] = oc[s * NPART + 1].x; lw[1] = oc[s * NPART + 1].y; lw[2] = oc[s * NPART + 1].z; lw[3] = oc[s * NPART + 1].w; }
+        for (int q = 0; q < 4; ++q) qc[i][q] = __builtin_amdgcn_raw_buffer_load_b128(qrs[i], qvo + q * 16, 0, 0);
+
+    for (int hin = 0; hin < NH; ++hin) {
+        const int hnext = hin + 1 < NH ? hin + 1 : hin;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int st = 2 * hin + s2;                      // stage st sits in slot st & 1 = s2
+            // my quarter of stage st (and, s2 = 0, this hin's product registers) has landed; after the barrier everybody's has, and
+            // every wave is done reading stage st - 1, whose slot the next stage is fetched into now
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (st + 1 < NSTG) dma_stage(st + 1, s2 ^ 1);
+            u32x4v ap[NXT][NT];
+#pragma unroll
+            for (int i = 0; i < NXT; ++i) {
+                float v[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    float f = bf2f((unsigned short)(hw[e >> 1] >> (16 * (e & 1))));
-                    if constexpr (NPART == 2) f += bf2f((unsigned short)(lw[e >> 1] >> (16 * (e & 1))));
-                    oldv[8 * s + e] = f;
+                    const unsigned w = qc[i][2 * s2 + (e >> 2)][e & 3];
+                    v[e] = bitsf(w);
                 }
+                split8_parts<NT>(v, ap[i]);
             }
-            write_delta_tiles<NH>(Fd, oldv, a, xt, h, lane_e);
-        }
-        if (store_fac) {
+            if (s2 == 1) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) Fac[(x0 + rho(r, half)) * Hp + hcol] = a[r];
-        }
-        if (want_tr) {
-            float q[16];
+                for (int i = 0; i < NXT; ++i)
 #pragma unroll
-            for (int qd = 0; qd < 4; ++qd) { q[4 * qd] = qc4[qd].x; q[4 * qd + 1] = qc4[qd].y; q[4 * qd + 2] = qc4[qd].z; q[4 * qd + 3] = qc4[qd].w; }
-            tr += (double)tile_dot_qb<true>(q, a, tbw, lane_e);
+                    for (int q = 0; q < 4; ++q) qc[i][q] = __builtin_amdgcn_raw_buffer_load_b128(qrs[i], qvo + q * 16, hnext * 4096, 0);
+            }
+            const u32x4v* tl = reinterpret_cast<const u32x4v*>(ring + s2 * STAGE * 1024) + lane;
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                u32x4v tb[NT];
+#pragma unroll
+                for (int p = 0; p < NT; ++p) tb[p] = tl[(h * NT + p) * 64];
+#pragma unroll
+                for (int pa = 0; pa < NT; ++pa)
+#pragma unroll
+                    for (int pb = 0; pa + pb < NT; ++pb)
+#pragma unroll
+                        for (int i = 0; i < NXT; ++i)
+                            acc[i][h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ap[i][pa]),
+                                                                               __builtin_bit_cast(bf16x8, tb[pb]), acc[i][h], 0, 0, 0);
+            }
         }
     }
-    if (want_tr) store_wave_dot(tr, trpart + blockIdx.x * 4 + wib, lane_e);
+    // the ring is dead once every wave has read the last stage: its space becomes the tail's transposition buffers
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (!active) {
+        if (trpart && lane == 0) trpart[blockIdx.x * 4 + wib] = 0.0;
+        return;
+    }
+    post_frag_tail<MODE, NH, NXT, BSIDE>(acc, In4, Fac, Ft, mask, hmask_start, XT, xt0, trpart, Fd, store_fac,
+                                         reinterpret_cast<float*>(ring) + wib * 32 * TB_LD, blockIdx.x * 4 + wib, lane);
 }
 
 // ---- fused post + Gram (NH <= 2), second form: the tile body of the register epilogue as its own kernel ------------------

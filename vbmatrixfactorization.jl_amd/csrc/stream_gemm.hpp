@@ -424,16 +424,7 @@ __global__ __launch_bounds__(256) void stream_gemm_kernel(const uint4* __restric
 // results differ by fp32 summation order only (measured 1.5e-6 of the largest element); they are deterministic.
 // Workgroups 0 and 1 may run the sweep's control chain on their first 256 threads (ctrl_kernels.hpp, ctrl_nthreads()).
 
-// one 1 KiB LDS-DMA piece: 64 lanes x 16 bytes from (descriptor, lane * 16 + soff) to lds + lane * 16 (lds wave-uniform).
-// (Plain functions, not inside the kernel template: with the address-space cast in the template's lambda hipcc (ROCm 7.2)
-// silently drops the HOST-side instantiation of the kernel -- no diagnostic, the launch stub is simply missing at link time.)
-__device__ __forceinline__ void lds_dma_piece(__amdgpu_buffer_rsrc_t r, unsigned char* lds, int voff, int soff) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
-}
-__device__ __forceinline__ void lds_dma_piece_nt(__amdgpu_buffer_rsrc_t r, unsigned char* lds, int voff, int soff) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 2);
-}
-
+// (lds_dma_piece / lds_dma_piece_nt: common.hpp)
 constexpr int LDS8_SLOT_BYTES = 24 * 1024;            // one k-step: NF factor fragments + the workgroup's Y tiles
 constexpr int LDS8_BYTES = 6 * LDS8_SLOT_BYTES;       // dynamic LDS of a launch (>= the control chain's need, ctrl_lds_bytes)
 

@@ -118,6 +118,7 @@ struct vbmf_ctx {
     int* sk_list = nullptr;                          // the segment list: int4 (block, first stage, stages, slab) per workgroup
     bool lds8 = true;                 // H >= 128, bf16x2 operands: the 512-thread LDS-DMA streaming kernel (env VBMF_LDS8=0: the per-wave kernel,
                                       // kept for A/B runs and for the fp32 / single-bf16 operand modes)
+    bool post3 = true;                // H >= 128 factor update with the table shared through LDS (post_frag3_kernel); VBMF_POST3=0: post_frag2
     bool P_frag = false;              // the Y'B product in c->P / c->Pred is fragment-major (stream_gemm.hpp, frag_out)
     bool B32_stale = false;           // the register epilogue skipped the fp32 store of B (inside vbmf_run): tiles are current
     int sready_seq = 0;               // sequence number of the Sigma-table release flag (register epilogue)
@@ -525,7 +526,8 @@ static int launch_post_frag(vbmf_ctx* c, int which = 1, const float* In = nullpt
     // row tiles per wave: 256 accumulator registers' worth on the long side; ONE on a short side (the 10k-row A side would
     // otherwise occupy 20 workgroups)
     const bool short_side = d.XT < 2048;
-    const int nxt = short_side ? 1 : (c->NH >= 8 ? VBMF_POST2_NXT8 : VBMF_POST2_NXT4);   // = PostFrag2Cfg<NH>::NXT
+    // post_frag3 (table through LDS, two workgroups per CU): 128 accumulator registers per wave on the long side
+    const int nxt = short_side ? 1 : (c->post3 ? (c->NH >= 8 ? 1 : 2) : (c->NH >= 8 ? VBMF_POST2_NXT8 : VBMF_POST2_NXT4));
     const int grid = (cdiv(d.XT, nxt) + 3) / 4;
     double* trp = (which == 1 && !c->diagvar && 4 * grid <= c->trpart_cap) ? c->trpart : nullptr;
     if (which == 1) c->ntr = trp ? 4 * grid : 0;
@@ -541,6 +543,25 @@ static int launch_post_frag(vbmf_ctx* c, int which = 1, const float* In = nullpt
 #define POST_FRAG2(NHc_, NXTc_, BS_)                                                                                              \
     hipLaunchKernelGGL((post_frag2_kernel<MODEc, NHc_, NXTc_, VBMF_POST_NT, BS_>), dim3(grid), dim3(256), 0, c->stream,           \
                        (const float4*)In, (const uint4*)c->SBf, Fac, Ft, mk, hstart, d.XT, stop, trp, fd, store_fac)
+#define POST_FRAG3(NHc_, NXTc_, BS_)                                                                                              \
+    hipLaunchKernelGGL((post_frag3_kernel<MODEc, NHc_, NXTc_, VBMF_POST_NT, BS_>), dim3(grid), dim3(256), 0, c->stream,           \
+                       (const float4*)In, (const uint4*)c->SBf, Fac, Ft, mk, hstart, d.XT, stop, trp, fd, store_fac)
+    if (c->post3) {
+        DISPATCH_MODE(c->mode, {
+            if constexpr (MODEc != MODE_F32) {
+                if (which == 0) {
+                    if (c->NH == 4) { if (short_side) POST_FRAG3(4, 1, false); else POST_FRAG3(4, 2, false); }
+                    else POST_FRAG3(8, 1, false);
+                } else {
+                    if (c->NH == 4) { if (short_side) POST_FRAG3(4, 1, true); else POST_FRAG3(4, 2, true); }
+                    else POST_FRAG3(8, 1, true);
+                }
+            }
+        });
+        HIPCHK(c, hipGetLastError());
+        return VBMF_OK;
+    }
+#undef POST_FRAG3
     DISPATCH_MODE(c->mode, {
         if constexpr (MODEc != MODE_F32) {
             if (which == 0) {
@@ -1122,6 +1143,7 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
     if (const char* e = getenv("VBMF_XCD_MAP")) c->xcd_map = atoi(e) != 0;      // A/B switch for the tuning record
     if (const char* e = getenv("VBMF_EPI_BALANCE")) c->epi_balance = atoi(e) != 0;
     if (const char* e = getenv("VBMF_LDS8")) c->lds8 = atoi(e) != 0;
+    if (const char* e = getenv("VBMF_POST3")) c->post3 = atoi(e) != 0;
     // H >= 128: one Gram workgroup per chunk (gram_tiles_kernel): enough chunks to fill the chip, few enough that the
     // fp64 reduction over the chunks' dense H x H slabs stays small (it was 412 us at 1M rows with 16-tile chunks)
     c->tiles_per_chunk = c->NH >= 4 ? (int)std::max<int64_t>(16, cdiv(cdiv(std::max(L, M), 32), 384)) : 32;
