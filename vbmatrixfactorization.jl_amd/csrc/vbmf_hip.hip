@@ -928,7 +928,7 @@ static int do_update_B(vbmf_ctx* c) {
     // H >= 128, un-split pass: the product travels fragment-major (16-byte accesses on both sides)
     // H <= 64 without the register epilogue (split pass on short row shards, narrow geometry): always fragment-major -- slabs
     // are folded element-wise and post_gram2_kernel reads the layout
-    const bool fragq = fused_gram(c) || c->d2.nsplit == 1;
+    const bool fragq = fused_gram(c) || c->d2.nsplit == 1 || use_lds8(c);
     if (fused_ctrl(c)) {
         TRY(launch_stream(c, 1, CTRL_COV_B | CTRL_EIG_BOLD, false, nullptr, fragq));
     } else if (side_overlap(c)) {
@@ -1176,7 +1176,9 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
         c->narrow = c->NH <= 2 && (ev ? atoi(ev) != 0 : groups <= 2);
     }
     plan_pass(c->d1, M, L, c->kstep, c->NH, c->Hp, ybytes, c->o.pass1_splits, c->narrow, 0, !use_lds8(c));
-    plan_pass(c->d2, L, M, c->kstep, c->NH, c->Hp, ybytes, 0, c->narrow, (c->NH == 2 && !c->narrow) ? VBMF_EPI_DY : 0);
+    int want2 = 0;                                   // tuning switch: split-K of the Y*A pass (H >= 128, LDS-DMA kernel only)
+    if (const char* e = getenv("VBMF_PASS2_SPLITS")) { if (use_lds8(c)) want2 = atoi(e); }
+    plan_pass(c->d2, L, M, c->kstep, c->NH, c->Hp, ybytes, want2, c->narrow, (c->NH == 2 && !c->narrow) ? VBMF_EPI_DY : 0);
     c->Mp = (int64_t)c->d1.XT * 32;
     c->Lp = (int64_t)c->d2.XT * 32;
     // the post kernel writes operand tiles for every 32-row tile of the factor: the consumer's KS must cover them
@@ -2199,7 +2201,7 @@ static int do_sparse_update_B(vbmf_ctx* c) {
     }
     // fragment-major product: H <= 64 always (folded element-wise when split), H >= 128 when un-split; the row-noise update
     // reads the plain product
-    const bool fragq = !c->diagvar && (fused_gram(c) || c->d2.nsplit == 1);
+    const bool fragq = !c->diagvar && (fused_gram(c) || c->d2.nsplit == 1 || use_lds8(c));
     TRY(launch_stream(c, 1, 0, false, nullptr, fragq));
     TRY(fold_Q_slabs(c));
     TRY(side_join(c));
