@@ -294,6 +294,12 @@ int vbmf_debug_time_pass(vbmf_ctx* ctx, int pass, int iters, double* ms);
 #define VBMF_DEBUG_SIGMA_B_PPM 2      /* test hook: the SigmaB / sigma2 table the B update multiplies by is scaled by (1 + value * 1e-6) --
                                          a deliberate, known-size regression that the parity asserts must catch (tests/test_gpu_soak.py) */
 int vbmf_debug_set(vbmf_ctx* ctx, int what, int64_t value);
+/* test hook for the spectral norm behind `delta` (src/util.jl:27-29: norm(::Matrix) of Julia 0.5 = the largest singular value; for the
+   H x H Gram the library keeps, its largest eigenvalue): lambda_max of the symmetric positive semi-definite H x H matrix G (column-major
+   doubles, H = the context's rank) by the SAME device kernel the run loop uses for that rank (H <= 64: repeated squaring + Rayleigh
+   quotient; H > 64: Lanczos), and the kernel's time in microseconds.  Overwrites the context's delta-Gram scratch (recomputed by every
+   sweep), nothing else. */
+int vbmf_debug_lambda_max(vbmf_ctx* ctx, const double* G, double* lambda_max, double* kernel_us);
 
 #ifdef __cplusplus
 }

@@ -31,7 +31,7 @@ SYMBOLS = [
     "vbmf_get_Y", "vbmf_get_trYY", "vbmf_set_state", "vbmf_get_state", "vbmf_step", "vbmf_run", "vbmf_run_fixed_basis",
     "vbmf_get_YHat",
     "vbmf_elbo", "vbmf_comm_unique_id", "vbmf_comm_init", "vbmf_comm_set_transport", "vbmf_profile_enable", "vbmf_profile_read",
-    "vbmf_pass_bytes", "vbmf_device_sync", "vbmf_debug_peek", "vbmf_debug_time_pass",
+    "vbmf_pass_bytes", "vbmf_device_sync", "vbmf_debug_peek", "vbmf_debug_time_pass", "vbmf_debug_lambda_max",
     "vbmf_sparse_set_state", "vbmf_sparse_get_state", "vbmf_sparse_step", "vbmf_sparse_run", "vbmf_sparse_run_fixed_basis",
     "vbmf_sparse_lower_bound", "vbmf_sparse_set_noise_rows", "vbmf_sparse_get_noise_rows", "vbmf_preprocess_open", "vbmf_preprocess_rows", "vbmf_set_Y_preprocessed",
     "vbmf_preprocess_close", "vbmf_dual_set_priors", "vbmf_dual_get_priors", "vbmf_dual_run",
@@ -118,6 +118,7 @@ def lib():
     L.vbmf_device_sync.argtypes = [vp]
     L.vbmf_debug_peek.argtypes = [vp, i32, C.POINTER(C.c_uint32), i64, i64]
     L.vbmf_debug_time_pass.argtypes = [vp, i32, i32, dp]
+    L.vbmf_debug_lambda_max.argtypes = [vp, dp, dp, dp]
     L.vbmf_sparse_set_state.argtypes = [vp, dp, dp, dp, dp, dp, i64, dp, dp, dp, C.c_double, C.c_double,
                                         C.POINTER(VbmfSparseHyper), C.POINTER(i64), i64, i64]
     L.vbmf_sparse_get_state.argtypes = [vp, dp, dp, dp, dp, dp, dp, i64, dp, dp, dp, dp, dp]
@@ -490,6 +491,14 @@ class Context:
         v = C.c_double()
         self._chk(self._lib.vbmf_debug_time_pass(self._h, p, iters, C.byref(v)))
         return v.value
+
+    def lambda_max(self, G):
+        """lambda_max of the symmetric PSD H x H matrix G by the device kernel the run loop uses for this rank; (value, kernel us)."""
+        G = np.asfortranarray(G, dtype=np.float64)
+        assert G.shape == (self.H, self.H)
+        v, us = C.c_double(), C.c_double()
+        self._chk(self._lib.vbmf_debug_lambda_max(self._h, _dptr(G), C.byref(v), C.byref(us)))
+        return v.value, us.value
 
     def sync(self):
         self._chk(self._lib.vbmf_device_sync(self._h))

@@ -3,7 +3,7 @@
 //   ctrl_cov_kernel   SigmaA = sigma2*inv(B'B + L*SigmaB + sigma2*inv(CA))   src/vbmf.jl:96-97
 //                     SigmaB = sigma2*inv(A'A + M*SigmaA + sigma2*inv(CB))   src/vbmf.jl:110-111
 //                     (register-tiled Gauss-Jordan, one barrier per pivot; log-determinant from the pivots)
-//   eig_kernel        lambda_max of the delta-Gram and of the B-Gram (repeated squaring + fp64 Rayleigh):
+//   eig_kernel        lambda_max of the delta-Gram and of the B-Gram (Lanczos on the register-resident matrix):
 //                     Julia 0.5 `norm(::Matrix)` is the spectral norm (src/util.jl:27-29)
 //   ctrl_end_kernel   updateCA!/updateCB! (src/vbmf.jl:129-146), updateSigma2! (src/vbmf.jl:153-157),
 //                     d (src/vbmf.jl:211), loop test (src/vbmf.jl:193), build-defined ELBO, trace record.
@@ -487,8 +487,184 @@ __global__ __launch_bounds__(T * T) void ctrl_cov_kernel(double* __restrict__ st
     ctrl_cov_dev<R, T>(st, lay, H, which, N, S32, ints, lds_cov);
 }
 
-// lambda_max of a symmetric PSD H x H matrix: block 0 -> GD (S_LAMD), block 1 -> GB (S_LAMB_NEW).
-// spectral = 0: Frobenius surrogate (trace) instead.
+// ---- lambda_max of a symmetric PSD matrix by LANCZOS on the register-resident matrix (H > 64) -------------------------------------
+// History.  H <= 128, rounds 1-3: ten repeated squarings of the LDS-resident fp32 matrix towards the dominant projector, then an fp64
+// Rayleigh quotient -- exact (1e-12) when the top gap exceeds 0.5 %, but up to 1.8e-4 off inside a cluster (measured 2.4e-4 on a spectrum
+// flat to 0.1 %: tests/test_gpu_lambda_max.py), 25 us at H = 64, 217 us at H = 128.  H > 128: power iteration from registers, 128 fixed
+// steps (round 2: ~1e-3 in a cluster), then to a tolerance capped at 2048 steps (round 3) -- which a FLAT spectrum (the delta-Gram of a
+// rank-256 fit to rank-16 data) runs into: 3.1 ms per call beside a 0.75 ms pass, and still only ~1e-4, because the power method's error
+// in a cluster falls like 1/k.  The Krylov space of the same matrix-vector products does far better (error ~ cosh(2 k sqrt(gap))^-2, exact
+// after H steps), for two block-wide dot products more per step:
+//     w = G q_j;  alpha_j = q_j'w;  w -= alpha_j q_j + beta_j q_(j-1);  beta_(j+1) = ||w||;  q_(j+1) = w / beta_(j+1)
+// and lambda_max(G) ~ the top eigenvalue of the tridiagonal T_k = tridiag(beta, alpha, beta), found by Sturm-count multisection
+// (256 shifts per round, 4 rounds: 2e-10 of the trace) at k = 12, 24, 36, 48, 64, 96, 128, 192, 256; the iteration ends when that
+// value grew by <= EIG_LANCZOS_TOL since the previous look, at an invariant subspace (beta = 0), or at k = H.  No re-orthogonalisation:
+// the copies of converged Ritz values that its absence breeds never exceed lambda_max.  Measured (tests/test_gpu_lambda_max.py: flat,
+// Marchenko-Pastur, near-degenerate pair, rank-deficient, dominant, 2^-k, identity): <= 8e-8 relative at H = 128, 130, 200, 256 (and at H = 40 when
+// routed here; H <= 64 keeps the squaring kernel below for its speed inside short pass launches).
+// Layout: NT threads (256 inside a pass launch and for 64 < H <= 128, 1024 for H > 128), matrix padded to NP = 16, 32, 64, 128 or 256.  Thread
+// (group = t / NCQ, cq = t % NCQ), NCQ = NP / 16, holds the RB x 16 block G[RB group .. +RB][16 cq .. +16] / tr in registers as fp32
+// pairs (the products go out as v_pk_fma_f32: a step is VALU-bound), reads its 16 entries of q from LDS (four 16-byte reads), forms RB
+// partial dot products and folds them over the NCQ chunks of its group with DPP moves.  Lane cq < RB of a group OWNS row RB group + cq:
+// it keeps q_j and q_(j-1) of that row in fp64.
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+// sum over the N (1, 2, 4, 8, 16; aligned) neighbouring lanes of a DPP row, the result in each of them: quad_perm [1,0,3,2], quad_perm
+// [2,3,0,1], row_half_mirror, row_mirror (cross-lane moves inside the VALU; __shfl_xor would be ds_bpermute round trips through LDS)
+template <int N>
+__device__ __forceinline__ float rowN_sum(float x) {
+    if constexpr (N >= 2) x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
+    if constexpr (N >= 4) x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));
+    if constexpr (N >= 8) x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));
+    if constexpr (N >= 16) x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x140, 0xF, 0xF, true));
+    return x;
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+    const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)u, CTRL, 0xF, 0xF, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(u >> 32), CTRL, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double lane_f64(double x, int l) {          // wave-uniform value of lane l
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, l);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), l);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+// sum over the first NT threads of the workgroup (whole waves), the wave stage on DPP + readlane (block_sum's six fp64 __shfl_down steps
+// are twelve ds_bpermute round trips); fixed order, every thread gets the same value.  red: NT / 64 doubles.
+template <int NT>
+__device__ __forceinline__ double block_sum_dpp(double x, double* red) {
+    x += dpp_f64<0xB1>(x);
+    x += dpp_f64<0x4E>(x);
+    x += dpp_f64<0x141>(x);
+    x += dpp_f64<0x140>(x);
+    const double wsum = (lane_f64(x, 0) + lane_f64(x, 16)) + (lane_f64(x, 32) + lane_f64(x, 48));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = wsum;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) s += red[i];
+    return s;
+}
+// top eigenvalue of the k x k tridiagonal (diagonal al[0..k), squared off-diagonals be2[1..k)) inside [lo, hi] (hi an upper bound of the
+// spectrum): `rounds` rounds of 256-way multisection on the Sturm count.  Threads 0..255 count, every thread returns the same value.
+__device__ __forceinline__ double tri_lambda_max(const double* al, const double* be2, int k, double lo, double hi, int* imin, int rounds) {
+    for (int r = 0; r < rounds; ++r) {
+        if (threadIdx.x == 0) *imin = 255;
+        __syncthreads();
+        const int t = threadIdx.x;
+        const double step = (hi - lo) * (1.0 / 256.0);
+        if (t < 256) {
+            const double x = t == 255 ? hi : lo + step * (double)(t + 1);
+            double d = al[0] - x;
+            int cnt = d < 0.0 ? 1 : 0;
+            for (int i = 1; i < k; ++i) {
+                if (fabs(d) < 1e-290) d = -1e-290;
+                d = al[i] - x - be2[i] * __builtin_amdgcn_rcp(d);
+                cnt += d < 0.0 ? 1 : 0;
+            }
+            if (cnt >= k) atomicMin(imin, t);                   // every eigenvalue lies below x
+        }
+        __syncthreads();
+        const int tm = *imin;
+        const double nhi = tm == 255 ? hi : lo + step * (double)(tm + 1);
+        const double nlo = tm == 0 ? lo : lo + step * (double)tm;
+        __syncthreads();                                        // (imin is reset at the top of the next round)
+        lo = nlo; hi = nhi;
+    }
+    return 0.5 * (lo + hi);
+}
+constexpr double EIG_LANCZOS_TOL = 2e-7;                        // growth of the top Ritz value between two looks, relative
+// LDS of a call: NP floats (q) + 2 NP + 1 doubles (alpha, beta^2) + 16 doubles + 1 int; the caller hands over >= EIG_LDS_BYTES
+constexpr int EIG_LDS_BYTES = 256 * 4 + (2 * 256 + 2) * 8 + 16 * 8 + 16;
+// lambda_max(G) / tr for the H x H matrix G (row stride Hp, H <= NP, tr = its trace > 0).  Every one of the NT threads gets the value.
+template <int NP, int NT>
+__device__ __forceinline__ double lanczos_lambda_max(const double* __restrict__ G, int Hp, int H, double tr, void* lds) {
+    constexpr int NCQ = NP / 16;
+    constexpr int RB = (NP * NCQ + NT - 1) / NT;                // rows per thread: 4 at NP = 128 / NT = 256 and NP = 256 / NT = 1024, else 1
+    static_assert(RB == 1 || RB == 4, "register block");
+    static_assert(NCQ >= RB, "one owner lane per row of the block");
+    float* vbuf = reinterpret_cast<float*>(lds);
+    double* al = reinterpret_cast<double*>(vbuf + 256);
+    double* be2 = al + 256;
+    double* red = be2 + 258;
+    int* imin = reinterpret_cast<int*>(red + 16);
+    const int t = threadIdx.x;
+    const int grp = t / NCQ, cq = t % NCQ;
+    const int row0 = grp * RB;
+    const bool active = row0 < NP;
+    const bool owner = active && cq < RB;
+    const int myrow = row0 + (cq % RB);
+    f32x2v g[RB][8];
+    {
+        const double inv = 1.0 / tr;                            // |G_ij| <= tr: entries in [-1, 1], lambda_max in (0, 1]
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int row = row0 + r, col = cq * 16 + j;
+                g[r][j >> 1][j & 1] = (active && row < H && col < H) ? (float)(G[(long long)row * Hp + col] * inv) : 0.f;
+            }
+    }
+    // start from the diagonal (a positive vector correlated with the dominant eigenvector of a PSD matrix)
+    double q = (owner && myrow < H) ? G[(long long)myrow * Hp + myrow] / tr + 1e-3 : 0.0, qp = 0.0, beta = 0.0;
+    {
+        const double n0 = block_sum_dpp<NT>(q * q, red);
+        q *= 1.0 / sqrt(n0);
+    }
+    if (owner) vbuf[myrow] = (float)q;
+    __syncthreads();
+    const int kmax = H < NP ? H : NP;
+    int next_look = 12;
+    double theta = 0.0, theta_prev = 0.0;
+    for (int j = 0; j < kmax; ++j) {
+        const float4* v4 = reinterpret_cast<const float4*>(&vbuf[cq * 16]);
+        f32x2v a2[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) a2[r] = f32x2v{0.f, 0.f};
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const float4 v = v4[jj];
+            const f32x2v va = {v.x, v.y}, vb = {v.z, v.w};
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                a2[r] = __builtin_elementwise_fma(g[r][2 * jj], va, a2[r]);
+                a2[r] = __builtin_elementwise_fma(g[r][2 * jj + 1], vb, a2[r]);
+            }
+        }
+        float acc[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) acc[r] = rowN_sum<NCQ>(a2[r][0] + a2[r][1]);
+        float mine = acc[0];
+        if constexpr (RB == 4) mine = (cq & 3) == 0 ? acc[0] : ((cq & 3) == 1 ? acc[1] : ((cq & 3) == 2 ? acc[2] : acc[3]));
+        double wv = owner ? (double)mine : 0.0;                 // (G q)[myrow]
+        const double alpha = block_sum_dpp<NT>(q * wv, red);    // (q = 0 outside the owner lanes)
+        wv = owner ? wv - alpha * q - beta * qp : 0.0;
+        const double b2 = block_sum_dpp<NT>(wv * wv, red);
+        const int k = j + 1;
+        if (t == 0) { al[j] = alpha; be2[k] = b2; }
+        const bool brk = !(b2 > 1e-28);                         // invariant subspace: T_k carries lambda_max of everything q_0 touches
+        qp = q;
+        beta = sqrt(b2);
+        q = brk ? 0.0 : wv / beta;
+        if (owner) vbuf[myrow] = (float)q;
+        __syncthreads();                                        // q_(j+1), alpha_j, beta_(j+1) are in LDS; every read of q_j is over
+        if (brk || k == next_look || k == kmax) {
+            theta = tri_lambda_max(al, be2, k, theta_prev > 1e-9 ? theta_prev - 1e-9 : 0.0, 1.0 + 1e-6, imin, 4);
+            if (brk || k == kmax || theta - theta_prev <= EIG_LANCZOS_TOL * theta) break;
+            theta_prev = theta;
+            next_look = k < 48 ? k + 12 : (k < 64 ? 64 : (k < 128 ? k + 32 : k + 64));
+        }
+    }
+    __syncthreads();                                            // the LDS is reused by whatever the block runs next
+    return theta;
+}
+
+// H <= 64: lambda_max by repeated squaring (kept for the small ranks: inside a 20-60 us pass launch of a narrow problem or a short row
+// shard its ~11 us (H = 32) / ~25 us (H = 64) are on the critical path, and the Lanczos iteration below, with its three barriers per step,
+// measured 2x slower there -- config 2 75 -> 126 us per sweep, the 8-way shard 163 -> 221).  spectral = 0: the trace instead.
 //
 // Method: NSQ repeated squarings T <- T*T / ||T*T||_F in fp32 (register-tiled, LDS-resident) drive T
 // to the dominant eigenprojector; its largest-diagonal column is then polished by two fp64 power
@@ -501,7 +677,7 @@ constexpr int EIG_NSQ = 10;
 
 // which = 0: GD -> S_LAMD, 1: GB -> S_LAMB_NEW.  256 threads, 2*NP*(NP+4) floats of LDS (NP = 16R).
 template <int R>
-__device__ __forceinline__ void eig_dev(double* __restrict__ st, StateLayout lay, int H, int spectral, int which,
+__device__ __forceinline__ void eig_squaring_dev(double* __restrict__ st, StateLayout lay, int H, int spectral, int which,
                                         const int* __restrict__ ints, float* ldsf, int slot) {
     __shared__ double red[16];
     __shared__ int s_arg;
@@ -601,6 +777,32 @@ __device__ __forceinline__ void eig_dev(double* __restrict__ st, StateLayout lay
     __syncthreads();                                         // LDS is reused by whatever the block runs next
 }
 
+// lambda_max of a symmetric PSD H x H matrix: which = 0: GD -> S_LAMD, 1: GB -> S_LAMB_NEW (the slot is the caller's).
+// spectral = 0: Frobenius surrogate (trace) instead.  256 threads (the first 256 of a 512-thread pass launch).  H <= 64: repeated squaring
+// (2 * NP * (NP + 4) floats of LDS); 64 < H <= 128: Lanczos (EIG_LDS_BYTES).
+template <int R>
+__device__ __forceinline__ void eig_dev(double* __restrict__ st, StateLayout lay, int H, int spectral, int which,
+                                        const int* __restrict__ ints, float* ldsf, int slot) {
+    if constexpr (R <= 4) {
+        eig_squaring_dev<R>(st, lay, H, spectral, which, ints, ldsf, slot);
+    } else {
+        __shared__ double red[16];
+        if (load_stop(ints)) return;
+        const int Hp = lay.Hp;
+        const double* G = st + (which == 0 ? lay.GD() : lay.GB());
+        double* scal = st + lay.scal();
+        double tr = 0.0;
+        for (int i = threadIdx.x; i < H; i += ctrl_nthreads()) tr += G[(long long)i * Hp + i];
+        tr = block_sum(tr, red);
+        if (!spectral || !(tr > 0.0) || !isfinite(tr)) {        // zero matrix -> 0; NaN propagates (loop exit on NaN d)
+            if (threadIdx.x == 0) scal[slot] = tr;
+            return;
+        }
+        const double theta = lanczos_lambda_max<16 * R, 256>(G, Hp, H, tr, ldsf);
+        if (threadIdx.x == 0) scal[slot] = tr * theta;
+    }
+}
+
 template <int R>
 __global__ __launch_bounds__(256) void eig_kernel(double* __restrict__ st, StateLayout lay, int H, int spectral,
                                                   int do_d, int do_b, const int* __restrict__ ints) {
@@ -610,25 +812,11 @@ __global__ __launch_bounds__(256) void eig_kernel(double* __restrict__ st, State
     eig_dev<R>(st, lay, H, spectral, which, ints, lds_eig, which == 0 ? S_LAMD : S_LAMB_NEW);
 }
 
-// H > 128 (the squaring kernel's two LDS tiles do not fit): power iteration with the matrix held in REGISTERS.
-// 1024 threads; thread (row = t/4, q = t%4) keeps G[row][64q .. 64q+63] / tr as 64 floats, the vector lives
-// in LDS (double-buffered: one barrier per iteration, normalised every 4th).  lambda = Rayleigh quotient of the
-// final vector, accumulated in fp64.  Converges like (lambda_2/lambda_1)^(2k) in the quotient.  (The first version walked the
-// fp64 matrix in global memory every iteration: 31 us per iteration, 3 ms per call at H = 256; this one is ~0.5 us per
-// iteration.  Round 2 ran a fixed 128 steps, which resolved near-degenerate top eigenvalues to ~1e-3 only.)
-// Round 3: the iteration runs to a TOLERANCE, not a fixed count.  Every fourth step the vector is normalised anyway, and the
-// norm it is divided by is ||G^4 v|| -> lambda^4: lam = (||G^4 v||^2)^(1/8) is an eigenvalue estimate that costs nothing.  The loop
-// ends when two successive estimates differ by <= EIG_POWER_TOL lam AND the geometric extrapolation of the remaining error
-// (diff * r / (1 - r), r = ratio of successive differences) is below the same bound -- so a slowly converging spectrum (top
-// eigenvalues 0.1 % apart: r ~ 0.99) is iterated on, up to EIG_POWER_MAX_ITERS steps, where the fixed 128 steps of round 2 left
-// ~1e-3; a well-separated one stops after 8-24 steps instead of 128 (this kernel sits beside -- at H = 256, since round 3's
-// streaming kernel, in FRONT of -- the Y'B pass: 0.8 ms for its 128 steps inside a pass).
-constexpr int EIG_POWER_MAX_ITERS = 2048;
-constexpr double EIG_POWER_TOL = 1e-6;
-__global__ __launch_bounds__(1024) void eig_power_kernel(double* __restrict__ st, StateLayout lay, int H, int spectral,
-                                                         int do_d, int do_b, const int* __restrict__ ints) {
+// H > 128: the same iteration on 1024 threads (NP = 256)
+__global__ __launch_bounds__(1024) void eig_lanczos_kernel(double* __restrict__ st, StateLayout lay, int H, int spectral,
+                                                           int do_d, int do_b, const int* __restrict__ ints) {
     __shared__ double red[16];
-    __shared__ __attribute__((aligned(16))) float vbuf[2][256];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_lz[EIG_LDS_BYTES];
     if (load_stop(ints)) return;
     const int which = blockIdx.x;           // 0: GD, 1: GB
     if ((which == 0 && !do_d) || (which == 1 && !do_b)) return;
@@ -637,68 +825,14 @@ __global__ __launch_bounds__(1024) void eig_power_kernel(double* __restrict__ st
     double* scal = st + lay.scal();
     const int slot = which == 0 ? S_LAMD : S_LAMB_NEW;
     double tr = 0.0;
-    for (int i = threadIdx.x; i < H; i += ctrl_nthreads()) tr += G[(long long)i * Hp + i];
+    for (int i = threadIdx.x; i < H; i += (int)blockDim.x) tr += G[(long long)i * Hp + i];
     tr = block_sum(tr, red);
     if (!spectral || !(tr > 0.0) || !isfinite(tr)) {
         if (threadIdx.x == 0) scal[slot] = tr;
         return;
     }
-    const int row = threadIdx.x >> 2, q = threadIdx.x & 3;      // 4 threads per row, 256 rows
-    float g[64];
-    {
-        const double inv = 1.0 / tr;                            // |G_ij| <= tr: entries in [-1, 1]
-#pragma unroll
-        for (int j = 0; j < 64; ++j) {
-            const int col = q * 64 + j;
-            g[j] = (row < H && col < H) ? (float)(G[(long long)row * Hp + col] * inv) : 0.f;
-        }
-    }
-    // start from the diagonal (a positive vector correlated with the dominant eigenvector of a PSD matrix)
-    if (threadIdx.x < 256) vbuf[0][threadIdx.x] = threadIdx.x < H ? (float)(G[(long long)threadIdx.x * Hp + threadIdx.x] / tr) + 1e-3f : 0.f;
-    __syncthreads();
-    int cur = 0;
-    double lam_prev = 0.0, diff_prev = 0.0;
-    for (int it = 0; it < EIG_POWER_MAX_ITERS; ++it) {
-        const float4* v4 = reinterpret_cast<const float4*>(&vbuf[cur][q * 64]);
-        float acc = 0.f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const float4 v = v4[j];
-            acc += g[4 * j] * v.x + g[4 * j + 1] * v.y + g[4 * j + 2] * v.z + g[4 * j + 3] * v.w;
-        }
-        acc += __shfl_xor(acc, 1);
-        acc += __shfl_xor(acc, 2);
-        bool done = false;
-        if ((it & 3) == 3) {                                    // entries shrink by >= 1/256 per step: safe for 4
-            double n1 = (q == 0) ? (double)acc * (double)acc : 0.0;
-            n1 = block_sum(n1, red);
-            acc = n1 > 0.0 ? (float)((double)acc / sqrt(n1)) : 0.f;
-            // (block_sum hands every thread the same n1: the test below is uniform)
-            const double lam = sqrt(sqrt(sqrt(n1)));            // (||G^4 v||^2)^(1/8), v normalised four steps ago (it >= 7)
-            const double diff = fabs(lam - lam_prev);
-            if (it >= 15) {                                     // lam is meaningful from it = 7, diff from 11, r from 15
-                const double r = diff_prev > 0.0 ? diff / diff_prev : 0.0;
-                const double rest = r < 0.999 ? diff * r / (1.0 - r) : 1.0;      // geometric tail of the remaining corrections
-                done = !(n1 > 0.0) || (diff <= EIG_POWER_TOL * lam && rest <= EIG_POWER_TOL * lam);
-            }
-            lam_prev = lam; diff_prev = diff;
-        }
-        if (q == 0) vbuf[cur ^ 1][row] = acc;
-        __syncthreads();
-        cur ^= 1;
-        if (done) break;
-    }
-    // Rayleigh quotient v'Gv / v'v, fp64 accumulation
-    double gv = 0.0;
-#pragma unroll
-    for (int j = 0; j < 64; ++j) gv += (double)g[j] * (double)vbuf[cur][q * 64 + j];
-    gv += __shfl_xor(gv, 1);
-    gv += __shfl_xor(gv, 2);
-    const double vi = (double)vbuf[cur][row];
-    double num = (q == 0) ? vi * gv : 0.0, den = (q == 0) ? vi * vi : 0.0;
-    num = block_sum(num, red);
-    den = block_sum(den, red);
-    if (threadIdx.x == 0) scal[slot] = den > 0.0 ? tr * num / den : 0.0;
+    const double theta = lanczos_lambda_max<256, 1024>(G, Hp, H, tr, lds_lz);
+    if (threadIdx.x == 0) scal[slot] = tr * theta;
 }
 
 // flags: bit0 est_covs->CA, bit1 est_covs->CB, bit2 est_var, bit3 compute d + loop bookkeeping,

@@ -338,8 +338,9 @@ static size_t ctrl_lds_bytes(int NH) {
     const int R = NH <= 4 ? 2 * NH : 0;
     if (R == 0) return 0;
     const size_t NP = 16 * (size_t)R;
-    // lambda_max (two NP x (NP + 4) fp32 images) | the blocked inverse's NP x (NP + 2) fp64 image (ctrl_kernels.hpp)
-    return std::max((size_t)2 * NP * (NP + 4) * sizeof(float), spd_inverse_lds_bytes(R));
+    // lambda_max (Lanczos vector + tridiagonal: EIG_LDS_BYTES) | the blocked inverse's NP x (NP + 2) fp64 image (ctrl_kernels.hpp)
+    const size_t eig = R <= 4 ? (size_t)2 * NP * (NP + 4) * sizeof(float) : (size_t)EIG_LDS_BYTES;      // squaring | Lanczos
+    return std::max(eig, spd_inverse_lds_bytes(R));
 }
 static bool fused_ctrl(const vbmf_ctx* c) { return c->in_run && c->NH <= 4; }
 
@@ -766,7 +767,7 @@ static int launch_ctrl_cov(vbmf_ctx* c, int which) {
 template <int R>
 static void launch_eig_t(vbmf_ctx* c, int do_d, int do_b, hipStream_t s) {
     constexpr int NP = 16 * R;
-    const size_t lds = (size_t)2 * NP * (NP + 4) * sizeof(float);
+    const size_t lds = R <= 4 ? (size_t)2 * NP * (NP + 4) * sizeof(float) : (size_t)EIG_LDS_BYTES;     // squaring | Lanczos
     const int spectral = (c->o.reference_compat & VBMF_COMPAT_SPECTRAL_DELTA) ? 1 : 0;
     hipLaunchKernelGGL((eig_kernel<R>), dim3(2), dim3(256), lds, s, c->st, c->lay, (int)c->H, spectral, do_d, do_b,
                        c->ints);
@@ -781,7 +782,7 @@ static int launch_eig(vbmf_ctx* c, int do_d, int do_b) {
     else if (H <= 128) launch_eig_t<8>(c, do_d, do_b, s);
     else {
         const int spectral = (c->o.reference_compat & VBMF_COMPAT_SPECTRAL_DELTA) ? 1 : 0;
-        hipLaunchKernelGGL(eig_power_kernel, dim3(2), dim3(1024), 0, s, c->st, c->lay, H, spectral, do_d, do_b, c->ints);
+        hipLaunchKernelGGL(eig_lanczos_kernel, dim3(2), dim3(1024), 0, s, c->st, c->lay, H, spectral, do_d, do_b, c->ints);
     }
     HIPCHK(c, hipGetLastError());
     return VBMF_OK;
@@ -928,7 +929,7 @@ static int do_update_B(vbmf_ctx* c) {
     // H >= 128, un-split pass: the product travels fragment-major (16-byte accesses on both sides)
     // H <= 64 without the register epilogue (split pass on short row shards, narrow geometry): always fragment-major -- slabs
     // are folded element-wise and post_gram2_kernel reads the layout
-    const bool fragq = fused_gram(c) || c->d2.nsplit == 1 || use_lds8(c);
+    const bool fragq = fused_gram(c) || c->d2.nsplit == 1;
     if (fused_ctrl(c)) {
         TRY(launch_stream(c, 1, CTRL_COV_B | CTRL_EIG_BOLD, false, nullptr, fragq));
     } else if (side_overlap(c)) {
@@ -1176,9 +1177,7 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
         c->narrow = c->NH <= 2 && (ev ? atoi(ev) != 0 : groups <= 2);
     }
     plan_pass(c->d1, M, L, c->kstep, c->NH, c->Hp, ybytes, c->o.pass1_splits, c->narrow, 0, !use_lds8(c));
-    int want2 = 0;                                   // tuning switch: split-K of the Y*A pass (H >= 128, LDS-DMA kernel only)
-    if (const char* e = getenv("VBMF_PASS2_SPLITS")) { if (use_lds8(c)) want2 = atoi(e); }
-    plan_pass(c->d2, L, M, c->kstep, c->NH, c->Hp, ybytes, want2, c->narrow, (c->NH == 2 && !c->narrow) ? VBMF_EPI_DY : 0);
+    plan_pass(c->d2, L, M, c->kstep, c->NH, c->Hp, ybytes, 0, c->narrow, (c->NH == 2 && !c->narrow) ? VBMF_EPI_DY : 0);
     c->Mp = (int64_t)c->d1.XT * 32;
     c->Lp = (int64_t)c->d2.XT * 32;
     // the post kernel writes operand tiles for every 32-row tile of the factor: the consumer's KS must cover them
@@ -1999,6 +1998,33 @@ int vbmf_debug_time_pass(vbmf_ctx* c, int pass, int iters, double* ms) {
     return rc;
 }
 
+int vbmf_debug_lambda_max(vbmf_ctx* c, const double* G, double* lam, double* kernel_us) {
+    if (!c || !G || !lam) return VBMF_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->o.device));
+    const int H = (int)c->H, Hp = c->Hp;
+    std::vector<double> g((size_t)Hp * Hp, 0.0);
+    for (int j = 0; j < H; ++j)
+        for (int i = 0; i < H; ++i) g[(size_t)i * Hp + j] = G[(size_t)j * H + i];
+    HIPCHK(c, hipMemcpyAsync(c->st + c->lay.GD(), g.data(), g.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->ints + I_STOP, 0, sizeof(int), c->stream));      // (the kernels are stop-gated)
+    hipEvent_t a, b;
+    HIPCHK(c, hipEventCreate(&a));
+    HIPCHK(c, hipEventCreate(&b));
+    hipEventRecord(a, c->stream);
+    int rc = launch_eig(c, 1, 0);
+    hipEventRecord(b, c->stream);
+    hipEventSynchronize(b);
+    float t = 0.f;
+    hipEventElapsedTime(&t, a, b);
+    hipEventDestroy(a);
+    hipEventDestroy(b);
+    if (rc != VBMF_OK) return rc;
+    HIPCHK(c, hipMemcpyAsync(lam, c->st + c->lay.scal() + S_LAMD, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (kernel_us) *kernel_us = 1e3 * (double)t;
+    return VBMF_OK;
+}
+
 int vbmf_debug_set(vbmf_ctx* c, int what, int64_t value) {
     if (!c) return VBMF_ERR_INVALID;
     switch (what) {
@@ -2201,7 +2227,7 @@ static int do_sparse_update_B(vbmf_ctx* c) {
     }
     // fragment-major product: H <= 64 always (folded element-wise when split), H >= 128 when un-split; the row-noise update
     // reads the plain product
-    const bool fragq = !c->diagvar && (fused_gram(c) || c->d2.nsplit == 1 || use_lds8(c));
+    const bool fragq = !c->diagvar && (fused_gram(c) || c->d2.nsplit == 1);
     TRY(launch_stream(c, 1, 0, false, nullptr, fragq));
     TRY(fold_Q_slabs(c));
     TRY(side_join(c));
