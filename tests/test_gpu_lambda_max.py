@@ -55,6 +55,51 @@ def test_lambda_max_on_hard_spectra(pkg, H):
             assert err <= tol, (H, name, got, ref, err)
 
 
+@pytest.mark.parametrize("H", [12, 40, 64])
+def test_lambda_max_exact_mode_at_small_ranks(pkg, H):
+    """VBMF_DEBUG_EXACT_LAMBDA (environment VBMF_EXACT_LAMBDA=1): the Lanczos iteration at H <= 64 too -- the flat spectrum that the default
+    squaring resolves to 2.2e-4 comes out to <= 1e-7 (measured 6e-8), like every other one."""
+    capi = pkg.capi
+    rng = np.random.default_rng(2000 + H)
+    with capi.Context(600, 300, H, y_dtype=capi.VBMF_Y_F32) as c:
+        c.debug_set(capi.DEBUG_EXACT_LAMBDA, 1)
+        for name, lam in _spectra(H, rng).items():
+            Gm = _with_spectrum(H, lam, 9 + H)
+            Gm = 0.5 * (Gm + Gm.T)
+            ref = float(np.linalg.eigvalsh(Gm)[-1])
+            got, us = c.lambda_max(Gm)
+            err = abs(got - ref) / ref
+            report(f"lambda_max exact mode H={H} {name}: lam={err:.2e}  [{us:.0f} us]")
+            assert err <= 2e-6, (H, name, got, ref, err)
+
+
+def test_exact_mode_run_matches_default_where_the_spectrum_is_separated(pkg):
+    """A whole run with the switch on: same stopping sweep and state as the default on a problem whose Grams have separated spectra (the two
+    methods agree to 1e-7 there), so the switch changes nothing but the clustered cases."""
+    from tests.helpers import to_pkg_params
+    from oracle import vbmf_oracle as O
+    import os
+    L, M, H = 300, 170, 5
+    rng = np.random.default_rng(77)
+    Y = rng.standard_normal((L, H)) @ (rng.standard_normal((H, M)) * np.linspace(3.0, 1.0, H)[:, None]) + 0.1 * rng.standard_normal((L, M))
+    pkg.set_defaults(y_dtype=pkg.VBMF_Y_F32, factor_dtype=pkg.VBMF_FACTOR_AUTO)
+    po = O.vbmf_init(Y, H, ca=1.0, cb=1.0, sigma2=1.0, rng=np.random.default_rng(5), materialize_yhat=False)
+    res = []
+    for exact in ("0", "1"):
+        os.environ["VBMF_EXACT_LAMBDA"] = exact
+        try:
+            pkg.invalidate()
+            pg = to_pkg_params(pkg, po)
+            pkg.vbmf_(Y, pg, 60, eps=1e-4, est_covs=True, est_var=True)
+            res.append((pg._last_run[0], pg._last_run[1], pg.AHat.copy()))
+        finally:
+            os.environ.pop("VBMF_EXACT_LAMBDA", None)
+            pkg.invalidate()
+    assert res[0][0] == res[1][0]
+    assert abs(res[0][1] - res[1][1]) <= 1e-6 * res[0][1]
+    assert np.array_equal(res[0][2], res[1][2])
+
+
 def test_lambda_max_degenerate_inputs(pkg):
     capi = pkg.capi
     H = 160

@@ -40,7 +40,7 @@ SYMBOLS = [
     "vbmf_sparse_lower_bound_trimmed", "vbmf_debug_set",
 ]
 VBMF_OK, VBMF_ERR_INVALID, VBMF_ERR_NO_DEVICE, VBMF_ERR_HIP, VBMF_ERR_NUMERIC, VBMF_ERR_COMM, VBMF_ERR_UNSUPPORTED, VBMF_ERR_SYNC = 0, -1, -2, -3, -4, -5, -6, -7
-DEBUG_EPI_SPIN_LIMIT, DEBUG_EPI_EXPECT_SKEW, DEBUG_SIGMA_B_PPM = 0, 1, 2
+DEBUG_EPI_SPIN_LIMIT, DEBUG_EPI_EXPECT_SKEW, DEBUG_SIGMA_B_PPM, DEBUG_EXACT_LAMBDA = 0, 1, 2, 3
 SSTEP_A, SSTEP_B, SSTEP_CA, SSTEP_CB, SSTEP_SIGMA, SSTEP_PRIORS = 1, 2, 4, 8, 16, 32
 PEEK_P, PEEK_Q, PEEK_A32, PEEK_B32, PEEK_FA, PEEK_FB, PEEK_Y1, PEEK_Y2, PEEK_DIMS, PEEK_CHAIN = range(10)
 

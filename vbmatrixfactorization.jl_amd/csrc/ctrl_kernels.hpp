@@ -783,8 +783,8 @@ __device__ __forceinline__ void eig_squaring_dev(double* __restrict__ st, StateL
 template <int R>
 __device__ __forceinline__ void eig_dev(double* __restrict__ st, StateLayout lay, int H, int spectral, int which,
                                         const int* __restrict__ ints, float* ldsf, int slot) {
-    if constexpr (R <= 4) {
-        eig_squaring_dev<R>(st, lay, H, spectral, which, ints, ldsf, slot);
+    if (R <= 4 && !(spectral & 2)) {                            // (uniform over the launch)
+        eig_squaring_dev<R>(st, lay, H, spectral & 1, which, ints, ldsf, slot);
     } else {
         __shared__ double red[16];
         if (load_stop(ints)) return;
@@ -794,7 +794,7 @@ __device__ __forceinline__ void eig_dev(double* __restrict__ st, StateLayout lay
         double tr = 0.0;
         for (int i = threadIdx.x; i < H; i += ctrl_nthreads()) tr += G[(long long)i * Hp + i];
         tr = block_sum(tr, red);
-        if (!spectral || !(tr > 0.0) || !isfinite(tr)) {        // zero matrix -> 0; NaN propagates (loop exit on NaN d)
+        if (!(spectral & 1) || !(tr > 0.0) || !isfinite(tr)) {  // zero matrix -> 0; NaN propagates (loop exit on NaN d)
             if (threadIdx.x == 0) scal[slot] = tr;
             return;
         }
@@ -827,7 +827,7 @@ __global__ __launch_bounds__(1024) void eig_lanczos_kernel(double* __restrict__ 
     double tr = 0.0;
     for (int i = threadIdx.x; i < H; i += (int)blockDim.x) tr += G[(long long)i * Hp + i];
     tr = block_sum(tr, red);
-    if (!spectral || !(tr > 0.0) || !isfinite(tr)) {
+    if (!(spectral & 1) || !(tr > 0.0) || !isfinite(tr)) {
         if (threadIdx.x == 0) scal[slot] = tr;
         return;
     }

@@ -118,6 +118,7 @@ struct vbmf_ctx {
     int* sk_list = nullptr;                          // the segment list: int4 (block, first stage, stages, slab) per workgroup
     bool lds8 = true;                 // H >= 128, bf16x2 operands: the 512-thread LDS-DMA streaming kernel (env VBMF_LDS8=0: the per-wave kernel,
                                       // kept for A/B runs and for the fp32 / single-bf16 operand modes)
+    bool exact_lambda = false;        // Lanczos lambda_max at H <= 64 too (vbmf_create: where a pass hides it; VBMF_EXACT_LAMBDA, vbmf_debug_set)
     bool post3 = true;                // H >= 128 factor update with the table shared through LDS (post_frag3_kernel); VBMF_POST3=0: post_frag2
     bool P_frag = false;              // the Y'B product in c->P / c->Pred is fragment-major (stream_gemm.hpp, frag_out)
     bool B32_stale = false;           // the register epilogue skipped the fp32 store of B (inside vbmf_run): tiles are current
@@ -332,6 +333,11 @@ static void prof_harvest(vbmf_ctx* c) {
     c->pev.clear();
 }
 
+// argument `spectral` of the lambda_max kernels: bit 0 = d uses spectral norms (else the trace), bit 1 = Lanczos at EVERY rank (H <= 64
+// otherwise keeps the repeated squaring: exact off clusters, up to ~2.5e-4 inside one, half the time inside short pass launches)
+static int spectral_arg(const vbmf_ctx* c) {
+    return ((c->o.reference_compat & VBMF_COMPAT_SPECTRAL_DELTA) ? 1 : 0) | (c->exact_lambda ? 2 : 0);
+}
 static bool use_lds8(const vbmf_ctx* c) { return c->lds8 && c->NH >= 4 && c->mode == MODE_BF16X2; }
 
 static size_t ctrl_lds_bytes(int NH) {
@@ -339,7 +345,7 @@ static size_t ctrl_lds_bytes(int NH) {
     if (R == 0) return 0;
     const size_t NP = 16 * (size_t)R;
     // lambda_max (Lanczos vector + tridiagonal: EIG_LDS_BYTES) | the blocked inverse's NP x (NP + 2) fp64 image (ctrl_kernels.hpp)
-    const size_t eig = R <= 4 ? (size_t)2 * NP * (NP + 4) * sizeof(float) : (size_t)EIG_LDS_BYTES;      // squaring | Lanczos
+    const size_t eig = std::max(R <= 4 ? (size_t)2 * NP * (NP + 4) * sizeof(float) : (size_t)0, (size_t)EIG_LDS_BYTES);      // squaring | Lanczos
     return std::max(eig, spd_inverse_lds_bytes(R));
 }
 static bool fused_ctrl(const vbmf_ctx* c) { return c->in_run && c->NH <= 4; }
@@ -374,7 +380,7 @@ static int launch_stream(vbmf_ctx* c, int pass, int ctrl_mode = 0, bool epi = fa
     ca.st = c->st; ca.lay = c->lay; ca.ints = c->ints; ca.trace = c->run_trace;
     ca.S32 = pass == 0 ? c->SA32 : c->SB32;
     ca.Lg = (double)c->Lg; ca.M = (double)c->M; ca.eps = c->run_eps;
-    ca.H = (int)c->H; ca.spectral = (c->o.reference_compat & VBMF_COMPAT_SPECTRAL_DELTA) ? 1 : 0;
+    ca.H = (int)c->H; ca.spectral = spectral_arg(c);
     ca.end_flags = c->run_flags; ca.mode = ctrl_mode; ca.it_row = (int)c->ends_enqueued;
     ea.frag_out = frag_out ? 1 : 0;
     if (epi) {
@@ -767,8 +773,8 @@ static int launch_ctrl_cov(vbmf_ctx* c, int which) {
 template <int R>
 static void launch_eig_t(vbmf_ctx* c, int do_d, int do_b, hipStream_t s) {
     constexpr int NP = 16 * R;
-    const size_t lds = R <= 4 ? (size_t)2 * NP * (NP + 4) * sizeof(float) : (size_t)EIG_LDS_BYTES;     // squaring | Lanczos
-    const int spectral = (c->o.reference_compat & VBMF_COMPAT_SPECTRAL_DELTA) ? 1 : 0;
+    const size_t lds = std::max(R <= 4 ? (size_t)2 * NP * (NP + 4) * sizeof(float) : (size_t)0, (size_t)EIG_LDS_BYTES);     // squaring | Lanczos
+    const int spectral = spectral_arg(c);
     hipLaunchKernelGGL((eig_kernel<R>), dim3(2), dim3(256), lds, s, c->st, c->lay, (int)c->H, spectral, do_d, do_b,
                        c->ints);
 }
@@ -781,7 +787,7 @@ static int launch_eig(vbmf_ctx* c, int do_d, int do_b) {
     else if (H <= 64) launch_eig_t<4>(c, do_d, do_b, s);
     else if (H <= 128) launch_eig_t<8>(c, do_d, do_b, s);
     else {
-        const int spectral = (c->o.reference_compat & VBMF_COMPAT_SPECTRAL_DELTA) ? 1 : 0;
+        const int spectral = spectral_arg(c);
         hipLaunchKernelGGL(eig_lanczos_kernel, dim3(2), dim3(1024), 0, s, c->st, c->lay, H, spectral, do_d, do_b, c->ints);
     }
     HIPCHK(c, hipGetLastError());
@@ -1175,6 +1181,16 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
         const int64_t Lnom = cdiv(c->Lg, c->o.nranks);
         const int64_t groups = std::min(cdiv(M, wq), cdiv(Lnom, wq));
         c->narrow = c->NH <= 2 && (ev ? atoi(ev) != 0 : groups <= 2);
+    }
+    {   // lambda_max at H <= 64: the Lanczos iteration (exact inside eigenvalue clusters too) where a pass is long enough to hide the control
+        // chain beside it -- >= 1 GB of Y per pass, ~160 us of streaming -- else the repeated squaring (half the time; on narrow problems and
+        // short row shards the chain IS the critical path: ctrl_kernels.hpp).  Decided on the NOMINAL shard size, like the geometry above:
+        // every rank of a row-sharded job must take the same loop-test decisions.  VBMF_EXACT_LAMBDA=0|1 forces it.
+        const int64_t Lnom = cdiv(c->Lg, c->o.nranks);
+        // (the basic model only: its chain rides inside the pass launches; the ARD-sparse variants issue lambda_max as a kernel of its own in
+        //  stream order, where the difference -- ~40 us at H = 64 -- is 2 % of config 5's H = 64 sweep)
+        c->exact_lambda = !c->sparse && (double)Lnom * (double)M * ybytes >= 1.0e9;
+        if (const char* e = getenv("VBMF_EXACT_LAMBDA")) c->exact_lambda = atoi(e) != 0;
     }
     plan_pass(c->d1, M, L, c->kstep, c->NH, c->Hp, ybytes, c->o.pass1_splits, c->narrow, 0, !use_lds8(c));
     plan_pass(c->d2, L, M, c->kstep, c->NH, c->Hp, ybytes, 0, c->narrow, (c->NH == 2 && !c->narrow) ? VBMF_EPI_DY : 0);
@@ -2028,6 +2044,9 @@ int vbmf_debug_lambda_max(vbmf_ctx* c, const double* G, double* lam, double* ker
 int vbmf_debug_set(vbmf_ctx* c, int what, int64_t value) {
     if (!c) return VBMF_ERR_INVALID;
     switch (what) {
+        case VBMF_DEBUG_EXACT_LAMBDA:
+            c->exact_lambda = value != 0;
+            return VBMF_OK;
         case VBMF_DEBUG_EPI_SPIN_LIMIT:
             if (value < 1 || value > (1ll << 30)) FAIL(c, VBMF_ERR_INVALID, "vbmf_debug_set: spin limit out of range");
             c->epi_spin_limit = (int)value;
