@@ -695,7 +695,7 @@ template <int NH> struct PostFrag2Cfg { static constexpr int NXT = NH >= 8 ? VBM
 
 // The tail of the H >= 128 factor update, shared by post_frag2_kernel and post_frag3_kernel: the wave's NXT x NH accumulator blocks
 // -> mask, operand tiles, delta tiles, fp32 factor, tr(B'YA) share.  `wslot` = this wave's slot in trpart ([4 * workgroups]).
-template <int MODE, int NH, int NXT, bool BSIDE>
+template <int MODE, int NH, int NXT, bool BSIDE, int AHEAD_MIN = 16>
 __device__ __forceinline__ void post_frag_tail(f32x16 (&acc)[NXT][NH], const float4* __restrict__ In4, float* __restrict__ Fac,
                                                uint4* __restrict__ Ft, const unsigned char* __restrict__ mask, int hmask_start,
                                                int XT, int xt0, double* __restrict__ trpart, uint4* __restrict__ Fd, int store_fac,
@@ -735,7 +735,7 @@ __device__ __forceinline__ void post_frag_tail(f32x16 (&acc)[NXT][NH], const flo
     };
     // (with half the accumulator registers or fewer, two or more waves run per SIMD and overlap each other's round trips: no
     //  read-ahead there, it would cost the 32 registers that keep the wave under 128 VGPRs)
-    constexpr bool AHEAD = NXT * NH >= 16;
+    constexpr bool AHEAD = NXT * NH >= AHEAD_MIN;
     if constexpr (AHEAD) request(0);
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
@@ -904,6 +904,9 @@ __global__ __launch_bounds__(256) void post_frag2_kernel(const float4* __restric
 // (NH * NT KiB) is brought into LDS once per workgroup by LDS-DMA (each wave a quarter), double-buffered one stage ahead behind ONE
 // raw barrier per stage; the waves read their B operands with ds_read_b128 (lane-linear, conflict-free).  128 accumulator registers
 // per wave (NXT = 1 at NH = 8, 2 at NH = 4) -> two workgroups per CU.  Same products in the same order as post_frag2: bit-identical.
+#ifndef VBMF_POST3_AHEAD_MIN
+#define VBMF_POST3_AHEAD_MIN 16     // blocks per wave from which the tail requests a block's reads one block ahead.  8 (every long-side launch; 256 VGPRs) measured no faster: 130 vs 122-125 us at 100k x 256, 64.6 vs 64.2 us at 125k x 128
+#endif
 template <int MODE, int NH, int NXT, int NT, bool BSIDE>
 __global__ __launch_bounds__(256, 2) void post_frag3_kernel(const float4* __restrict__ In4, const uint4* __restrict__ Sf,
                                                             float* __restrict__ Fac, uint4* __restrict__ Ft,
@@ -1004,7 +1007,7 @@ __global__ __launch_bounds__(256, 2) void post_frag3_kernel(const float4* __rest
         if (trpart && lane == 0) trpart[blockIdx.x * 4 + wib] = 0.0;
         return;
     }
-    post_frag_tail<MODE, NH, NXT, BSIDE>(acc, In4, Fac, Ft, mask, hmask_start, XT, xt0, trpart, Fd, store_fac,
+    post_frag_tail<MODE, NH, NXT, BSIDE, VBMF_POST3_AHEAD_MIN>(acc, In4, Fac, Ft, mask, hmask_start, XT, xt0, trpart, Fd, store_fac,
                                          reinterpret_cast<float*>(ring) + wib * 32 * TB_LD, blockIdx.x * 4 + wib, lane);
 }
 
