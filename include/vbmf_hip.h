@@ -294,9 +294,9 @@ int vbmf_debug_time_pass(vbmf_ctx* ctx, int pass, int iters, double* ms);
 #define VBMF_DEBUG_SIGMA_B_PPM 2      /* test hook: the SigmaB / sigma2 table the B update multiplies by is scaled by (1 + value * 1e-6) --
                                          a deliberate, known-size regression that the parity asserts must catch (tests/test_gpu_soak.py) */
 #define VBMF_DEBUG_EXACT_LAMBDA 3      /* lambda_max of the spectral norms at H <= 64: != 0 the Lanczos iteration every larger rank uses (exact inside
-                                         eigenvalue clusters too), 0 the repeated squaring (exact off clusters, up to ~2.5e-4 inside one, half the
-                                         time).  vbmf_create picks Lanczos for the basic model where a pass streams >= 1 GB of Y and hides it, squaring on narrow
-                                         problems, short row shards and the ARD-sparse variants, where the control algebra is on the critical path; environment VBMF_EXACT_LAMBDA=0|1 forces it. */
+                                         eigenvalue clusters too), 0 (default) the repeated squaring: exact off clusters, up to ~2.5e-4 inside one, and
+                                         faster -- 0.3-0.6 % of the sweep rate at 100k x 10k, 40 % on narrow problems and short row shards, where the
+                                         control chain is the critical path.  Environment VBMF_EXACT_LAMBDA=1 at vbmf_create sets it for a whole job. */
 int vbmf_debug_set(vbmf_ctx* ctx, int what, int64_t value);
 /* test hook for the spectral norm behind `delta` (src/util.jl:27-29: norm(::Matrix) of Julia 0.5 = the largest singular value; for the
    H x H Gram the library keeps, its largest eigenvalue): lambda_max of the symmetric positive semi-definite H x H matrix G (column-major

@@ -118,7 +118,7 @@ struct vbmf_ctx {
     int* sk_list = nullptr;                          // the segment list: int4 (block, first stage, stages, slab) per workgroup
     bool lds8 = true;                 // H >= 128, bf16x2 operands: the 512-thread LDS-DMA streaming kernel (env VBMF_LDS8=0: the per-wave kernel,
                                       // kept for A/B runs and for the fp32 / single-bf16 operand modes)
-    bool exact_lambda = false;        // Lanczos lambda_max at H <= 64 too (vbmf_create: where a pass hides it; VBMF_EXACT_LAMBDA, vbmf_debug_set)
+    bool exact_lambda = false;        // Lanczos lambda_max at H <= 64 too (VBMF_EXACT_LAMBDA=1, vbmf_debug_set(VBMF_DEBUG_EXACT_LAMBDA))
     bool post3 = true;                // H >= 128 factor update with the table shared through LDS (post_frag3_kernel); VBMF_POST3=0: post_frag2
     bool P_frag = false;              // the Y'B product in c->P / c->Pred is fragment-major (stream_gemm.hpp, frag_out)
     bool B32_stale = false;           // the register epilogue skipped the fp32 store of B (inside vbmf_run): tiles are current
@@ -1182,16 +1182,12 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
         const int64_t groups = std::min(cdiv(M, wq), cdiv(Lnom, wq));
         c->narrow = c->NH <= 2 && (ev ? atoi(ev) != 0 : groups <= 2);
     }
-    {   // lambda_max at H <= 64: the Lanczos iteration (exact inside eigenvalue clusters too) where a pass is long enough to hide the control
-        // chain beside it -- >= 1 GB of Y per pass, ~160 us of streaming -- else the repeated squaring (half the time; on narrow problems and
-        // short row shards the chain IS the critical path: ctrl_kernels.hpp).  Decided on the NOMINAL shard size, like the geometry above:
-        // every rank of a row-sharded job must take the same loop-test decisions.  VBMF_EXACT_LAMBDA=0|1 forces it.
-        const int64_t Lnom = cdiv(c->Lg, c->o.nranks);
-        // (the basic model only: its chain rides inside the pass launches; the ARD-sparse variants issue lambda_max as a kernel of its own in
-        //  stream order, where the difference -- ~40 us at H = 64 -- is 2 % of config 5's H = 64 sweep)
-        c->exact_lambda = !c->sparse && (double)Lnom * (double)M * ybytes >= 1.0e9;
-        if (const char* e = getenv("VBMF_EXACT_LAMBDA")) c->exact_lambda = atoi(e) != 0;
-    }
+    // lambda_max at H <= 64: the repeated squaring unless asked otherwise (VBMF_EXACT_LAMBDA=1: the Lanczos iteration every larger rank
+    // uses, exact inside eigenvalue clusters too).  Measured at the headline (scripts/r03_exact_ab.sh, profiles/r03_k_lambda_max.txt): the
+    // Lanczos chain inside the pass launches costs 0.3 % (200 sweeps) to 0.6 % (the driver's 20: the last sweep's stand-alone tail) of the
+    // sweep rate and moves `d` in no digit a comparison shows; on narrow problems and short row shards, where the chain is the critical
+    // path, 40 %.  A switch for every rank of a job alike (the loop-test decisions must agree).
+    if (const char* e = getenv("VBMF_EXACT_LAMBDA")) c->exact_lambda = atoi(e) != 0;
     plan_pass(c->d1, M, L, c->kstep, c->NH, c->Hp, ybytes, c->o.pass1_splits, c->narrow, 0, !use_lds8(c));
     plan_pass(c->d2, L, M, c->kstep, c->NH, c->Hp, ybytes, 0, c->narrow, (c->NH == 2 && !c->narrow) ? VBMF_EPI_DY : 0);
     c->Mp = (int64_t)c->d1.XT * 32;
