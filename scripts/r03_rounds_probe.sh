@@ -1,4 +1,5 @@
 #!/bin/bash
+# SUPERSEDED by scripts/r03_rounds_alone.py (this version did not print the planner's split count: two of its four rows were split launches).
 # Does config 5's Y*A pass (391 workgroups of 8 x tiles on 256 CUs) scale with its ROUNDS or with its WORK?  The same shape with L chosen so
 # that the pass is exactly one round (254 workgroups), what config 5 has (391), and two full rounds (508).   gpurun -- bash scripts/r03_rounds_probe.sh
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R

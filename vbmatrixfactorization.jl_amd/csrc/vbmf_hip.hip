@@ -1228,9 +1228,9 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
         const int bps2 = cdiv(c->d2.XT, xpw), nst = c->d2.steps_per_split / 2;
         const int nfull = bps2 / NUM_CU * NUM_CU, R = bps2 - nfull;
         // OFF unless VBMF_STREAMK=1 -- measured, not faster (profiles/r03_g_segment_list_ab.txt): config 5's Y*A pass 0.80 ms + a
-        // 0.04 ms fix-up against 0.83 ms for the plain two rounds (391 blocks on 254 CUs, nominally 77 % efficient).  These passes run at
-        // the chip's power limit: while the second round keeps only 137 CUs busy the clock rises, so the schedule's idle CUs cost far
-        // less than their count says -- the time is set by the MFMA work, not by how it is dealt.  (An earlier cut at arbitrary stages,
+        // 0.04 ms fix-up against 0.83 ms for the plain two rounds (391 blocks on 254 CUs, nominally 77 % efficient).  Alone, a full round
+        // of 254 workgroups takes 0.48 ms and the second round of 137 only 0.34 (fewer workgroups in flight run faster each): the schedule's
+        // idle CUs cost ~80 us against a perfect balance, far less than their count says (profiles/r03_i_pass2_probes.txt).  (An earlier cut at arbitrary stages,
         // every workgroup at its own k, was 25 % SLOWER: the factor then comes from beyond L2.)  Kept as a tested switch.
         if (use_lds8(c) && c->d2.nsplit == 1 && nfull > 0 && R > 0 && (double)R / NUM_CU < 0.8 && (ev && atoi(ev) == 1)) {
             int bestT = 0;
