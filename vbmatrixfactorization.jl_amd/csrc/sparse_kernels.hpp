@@ -14,6 +14,7 @@
 #pragma once
 #include "common.hpp"
 #include "ctrl_kernels.hpp"
+#include "post_kernels.hpp"
 
 namespace vbmf {
 
@@ -60,6 +61,74 @@ __global__ __launch_bounds__(256) void sparse_update_a_kernel(const float* __res
         }
         A32[i] = a;
         dS32[i] = ds;
+    }
+}
+
+// The same update with the operand tiles of the next pass written in the same kernel (sparse_update_a_kernel + retile_kernel in one, value for
+// value): one wave per 32-row tile of A, the 32 x 32 block of the product brought in as whole 128-byte rows of P and turned through the wave's
+// LDS tile (sparse_update_a_kernel's threads walk P down its columns, 40 KB apart: 8 x the bytes), the block formed in the accumulator-tile
+// layout write_factor_tiles takes (lane = column h, registers = rows), A32 stored as the value the tiles encode.  At 10k x 256 (config 5):
+// update_a 22-26 us + retile 16 us -> one launch of ~12 us.
+template <int MODE, int NH>
+__global__ __launch_bounds__(256) void sparse_update_a_tiles_kernel(const float* __restrict__ P, long long ldP,
+                                                                    const float* __restrict__ CA32, const double* __restrict__ v,
+                                                                    const double* __restrict__ st, StateLayout lay,
+                                                                    float* __restrict__ A32, float* __restrict__ dS32,
+                                                                    uint4* __restrict__ Ft,
+                                                                    const unsigned char* __restrict__ mask, int hmask_start,
+                                                                    long long M, int H, int compat, int unit_sigma, int XT,
+                                                                    const int* __restrict__ stop) {
+    constexpr int Hp = NH * 32;
+    __shared__ float tbuf[4][32 * TB_LD];
+    if (stop && *stop) return;
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    // one wave per (row tile, column tile) block: XT * NH waves (one wave per row tile walking its NH blocks in turn was 2 % SLOWER than the
+    // two kernels it replaces at 10k x 256 -- 313 waves for 2.5 M fp64 divisions)
+    const int wv = blockIdx.x * 4 + wib;
+    const int xt = wv / NH, h = wv % NH;
+    if (xt >= XT) return;                                   // (no workgroup barrier below: the LDS tile is the wave's own)
+    float* tb = tbuf[wib];
+    const int c = lane & 31, half = lane >> 5;
+    const int hr = lane >> 1, seg = lane & 1;               // the load's view: row hr of the block, 16 columns from 16 seg
+    const long long x0 = (long long)xt * 32;
+    const double sig = unit_sigma ? 1.0 : st[lay.scal() + S_SIGMA2];
+    {
+        const float4* src = reinterpret_cast<const float4*>(P + (long long)(h * 32 + hr) * ldP + x0 + seg * 16);
+        float4 pv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pv[j] = src[j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float* d = tb + hr * TB_LD + seg * 16 + 4 * j;
+            d[0] = pv[j].x; d[1] = pv[j].y; d[2] = pv[j].z; d[3] = pv[j].w;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+        const int hcol = h * 32 + c;
+        f32x16 a, ds;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int xr = rho(r, half);
+            const long long m = x0 + xr;
+            float av = 0.f, dv = 0.f;
+            if (m < M && hcol < H) {
+                const long long p = m * H + hcol;                              // 0-based position in vec(A')
+                long long vi = hcol;
+                if (compat) vi = (p < H) ? p : (p - H) / (M - 1);              // repeat(v, inner = M-1) after the first H
+                const double prec = v[vi] + (double)CA32[m * Hp + hcol];
+                const double dd = 1.0 / prec;
+                dv = (float)dd;
+                av = (float)(sig * dd * (double)tb[c * TB_LD + xr]);
+                if (mask != nullptr && hcol >= hmask_start && mask[m]) av = 0.f;
+            }
+            a[r] = av; ds[r] = dv;
+        }
+        write_factor_tiles<MODE, NH>(Ft, a, xt, h, lane);                       // a := the value the tiles encode
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long long m = x0 + rho(r, half);
+            if (m < M) { A32[m * Hp + hcol] = a[r]; dS32[m * Hp + hcol] = ds[r]; }
+        }
     }
 }
 

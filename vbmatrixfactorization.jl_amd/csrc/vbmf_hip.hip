@@ -119,6 +119,7 @@ struct vbmf_ctx {
     bool lds8 = true;                 // H >= 128, bf16x2 operands: the 512-thread LDS-DMA streaming kernel (env VBMF_LDS8=0: the per-wave kernel,
                                       // kept for A/B runs and for the fp32 / single-bf16 operand modes)
     bool exact_lambda = false;        // Lanczos lambda_max at H <= 64 too (VBMF_EXACT_LAMBDA=1, vbmf_debug_set(VBMF_DEBUG_EXACT_LAMBDA))
+    bool sparse_a_fused = true;       // ARD-sparse A update writes its operand tiles itself (VBMF_SPARSE_A_FUSED=0: update kernel + retile)
     bool post3 = true;                // H >= 128 factor update with the table shared through LDS (post_frag3_kernel); VBMF_POST3=0: post_frag2
     bool P_frag = false;              // the Y'B product in c->P / c->Pred is fragment-major (stream_gemm.hpp, frag_out)
     bool B32_stale = false;           // the register epilogue skipped the fp32 store of B (inside vbmf_run): tiles are current
@@ -1151,6 +1152,7 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
     if (const char* e = getenv("VBMF_EPI_BALANCE")) c->epi_balance = atoi(e) != 0;
     if (const char* e = getenv("VBMF_LDS8")) c->lds8 = atoi(e) != 0;
     if (const char* e = getenv("VBMF_POST3")) c->post3 = atoi(e) != 0;
+    if (const char* e = getenv("VBMF_SPARSE_A_FUSED")) c->sparse_a_fused = atoi(e) != 0;
     // H >= 128: one Gram workgroup per chunk (gram_tiles_kernel): enough chunks to fill the chip, few enough that the
     // fp64 reduction over the chunks' dense H x H slabs stays small (it was 412 us at 1M rows with 16-tile chunks)
     c->tiles_per_chunk = c->NH >= 4 ? (int)std::max<int64_t>(16, cdiv(cdiv(std::max(L, M), 32), 384)) : 32;
@@ -2216,12 +2218,23 @@ static int do_sparse_update_A(vbmf_ctx* c, bool reuse_P = false) {
                        c->diagvar ? (const double*)c->vsq : (const double*)nullptr, stop);
     const int compat = (c->o.reference_compat & VBMF_COMPAT_SPARSE_REPEAT) ? 1 : 0;
     if (compat && c->M < 2) FAIL(c, VBMF_ERR_INVALID, "repeat(v, inner=M-1) needs M >= 2");
-    hipLaunchKernelGGL(sparse_update_a_kernel, dim3(grid_for((int64_t)c->M * c->Hp)), dim3(256), 0, c->stream, c->Pred,
-                       (long long)c->d1.XT * 32, c->CA32, c->vtab, c->st, c->lay, c->A32, c->dS32,
-                       c->has_mask ? c->mask : nullptr, (int)(c->H - c->H1), (long long)c->M, (int)c->H, c->Hp, compat,
-                       c->diagvar ? 1 : 0, stop);
-    HIPCHK(c, hipGetLastError());
-    TRY(launch_retile(c, 0, true));                 // operand tiles; A32 := the value the tiles encode
+    if (c->sparse_a_fused) {
+        // the update and the operand tiles of the next pass in one launch (A32 := the value the tiles encode, as retile leaves it)
+        DISPATCH_MODE(c->mode, DISPATCH_NH(c->NH, {
+            hipLaunchKernelGGL((sparse_update_a_tiles_kernel<MODEc, NHc>), dim3((c->d1.XT * NHc + 3) / 4), dim3(256), 0, c->stream, c->Pred,
+                               (long long)c->d1.XT * 32, c->CA32, c->vtab, c->st, c->lay, c->A32, c->dS32, c->FA,
+                               c->has_mask ? c->mask : nullptr, (int)(c->H - c->H1), (long long)c->M, (int)c->H, compat,
+                               c->diagvar ? 1 : 0, c->d1.XT, stop);
+        }));
+        HIPCHK(c, hipGetLastError());
+    } else {
+        hipLaunchKernelGGL(sparse_update_a_kernel, dim3(grid_for((int64_t)c->M * c->Hp)), dim3(256), 0, c->stream, c->Pred,
+                           (long long)c->d1.XT * 32, c->CA32, c->vtab, c->st, c->lay, c->A32, c->dS32,
+                           c->has_mask ? c->mask : nullptr, (int)(c->H - c->H1), (long long)c->M, (int)c->H, c->Hp, compat,
+                           c->diagvar ? 1 : 0, stop);
+        HIPCHK(c, hipGetLastError());
+        TRY(launch_retile(c, 0, true));             // operand tiles; A32 := the value the tiles encode
+    }
     TRY(launch_gram(c, 0, c->A32, nullptr, true));
     TRY(sparse_colsum(c));                          // SigmaA = diag(sum_m diagSigma)
     c->gA_valid = true;
