@@ -2304,7 +2304,7 @@ static int do_hetero_sigma(vbmf_ctx* c) {
 }
 
 static int sparse_update_CA(vbmf_ctx* c) {
-    hipLaunchKernelGGL(sparse_update_ca_kernel, dim3(grid_for((int64_t)c->M * c->Hp)), dim3(256), 0, c->stream, c->A32, c->dS32,
+    hipLaunchKernelGGL(sparse_update_ca_kernel, dim3(grid_for((int64_t)c->M * c->Hp)), dim3(256), 0, ctrl_stream(c), c->A32, c->dS32,
                        c->beta32, c->CA32, c->alpha, c->hyp.beta0, (long long)c->M, (int)c->H, c->Hp, c->ints + I_STOP,
                        c->dual ? c->st + c->lay.scal() : (double*)nullptr, (int)c->H0, (long long)c->M0,
                        c->dual ? c->gpart : (double*)nullptr);
@@ -2536,11 +2536,15 @@ static int sparse_run_impl(vbmf_ctx* c, int64_t niter, double eps, int est_cb, i
     while (rc == VBMF_OK && it < niter && !stopped) {
         rc = do_sparse_update_A(c);
         if (rc == VBMF_OK) rc = do_sparse_update_B(c);
-        if (rc == VBMF_OK) rc = sparse_update_CA(c);
+        // updateCA! reads what the A update left and writes what the NEXT A update reads: with a side stream (H > 128) it runs there too,
+        // beside the next sweep's Y'B pass, instead of 13 us between the sweeps (not with the group priors or the row noise behind it)
+        const bool ca_on_side = side_overlap(c) && !est_priors && !c->diagvar;
+        if (rc == VBMF_OK && !ca_on_side) rc = sparse_update_CA(c);
         if (rc == VBMF_OK && est_priors) rc = dual_update_priors(c);      // depends on updateCA!'s outputs only
         if (rc == VBMF_OK && c->diagvar) rc = do_hetero_sigma(c);
         // lambda_max, CB, sigma, d and the stop test: beside the next sweep's Y'B pass when they run on the side stream
         if (rc == VBMF_OK && side_overlap(c)) rc = side_fork(c);
+        if (rc == VBMF_OK && ca_on_side) rc = sparse_update_CA(c);
         const bool t2_ahead = c->use_side && !c->diagvar;        // (diag_var: no scalar noise update, t2 is not used)
         if (rc == VBMF_OK && t2_ahead) rc = launch_sparse_t2(c);   // 64 workgroups, before the long lambda_max kernel
         if (rc == VBMF_OK) rc = launch_eig(c, 1, 1);
