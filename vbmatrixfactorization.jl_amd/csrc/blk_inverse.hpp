@@ -105,7 +105,7 @@ __device__ __forceinline__ double bperm_f64(int addr, double v) {
     return __hiloint2double(hi, lo);
 }
 template <int KK>
-__device__ __forceinline__ void sweep16_step(f64x4& a, double& u, int c, int q, const int (&rowaddr)[4], PivAcc& pv) {
+__device__ __forceinline__ void sweep16_step(f64x4& a, double& u, int c, int q, const int (&rowaddr)[4], PivAcc& pv, double* pivout) {
     constexpr int Q0 = KK & 3, R0 = KK >> 2;
     constexpr int Q1 = (KK + 1) & 3, R1 = ((KK + 1) >> 2) & 3;
     double un = 0.0;
@@ -115,6 +115,7 @@ __device__ __forceinline__ void sweep16_step(f64x4& a, double& u, int c, int q, 
     for (int r = 0; r < 4; ++r) v[r] = row_bcast16<KK>(a[r]);    // A[q + 4r][k]
     const double d = row_bcast16<KK>(u);                         // A[k][k]
     pv.push(d);
+    if (pivout != nullptr && c == 0 && q == 0) pivout[KK] = d;   // (optional: the pivots one by one, for callers that fold them themselves)
     const double dinv = blk_rcp(d);
     const bool is_col = (c == KK), is_row = (q == Q0);
     const double w = is_col ? -dinv : u * dinv;
@@ -126,16 +127,16 @@ __device__ __forceinline__ void sweep16_step(f64x4& a, double& u, int c, int q, 
         u = fma(-vk1, w, zero_if(is_col, un));                   // row k+1 after it
     }
 }
-__device__ __forceinline__ void sweep16(f64x4& a, int lane, PivAcc& pv) {
+__device__ __forceinline__ void sweep16(f64x4& a, int lane, PivAcc& pv, double* pivout = nullptr) {
     const int c = lane & 15, q = lane >> 4;
     const int rowaddr[4] = {4 * c, 4 * (16 + c), 4 * (32 + c), 4 * (48 + c)};      // ds_bpermute byte addresses of lane (c, row Q)
     double u = bperm_f64(rowaddr[0], a[0]);                      // row 0
-    sweep16_step<0>(a, u, c, q, rowaddr, pv);  sweep16_step<1>(a, u, c, q, rowaddr, pv);  sweep16_step<2>(a, u, c, q, rowaddr, pv);
-    sweep16_step<3>(a, u, c, q, rowaddr, pv);  sweep16_step<4>(a, u, c, q, rowaddr, pv);  sweep16_step<5>(a, u, c, q, rowaddr, pv);
-    sweep16_step<6>(a, u, c, q, rowaddr, pv);  sweep16_step<7>(a, u, c, q, rowaddr, pv);  sweep16_step<8>(a, u, c, q, rowaddr, pv);
-    sweep16_step<9>(a, u, c, q, rowaddr, pv);  sweep16_step<10>(a, u, c, q, rowaddr, pv); sweep16_step<11>(a, u, c, q, rowaddr, pv);
-    sweep16_step<12>(a, u, c, q, rowaddr, pv); sweep16_step<13>(a, u, c, q, rowaddr, pv); sweep16_step<14>(a, u, c, q, rowaddr, pv);
-    sweep16_step<15>(a, u, c, q, rowaddr, pv);
+    sweep16_step<0>(a, u, c, q, rowaddr, pv, pivout);  sweep16_step<1>(a, u, c, q, rowaddr, pv, pivout);  sweep16_step<2>(a, u, c, q, rowaddr, pv, pivout);
+    sweep16_step<3>(a, u, c, q, rowaddr, pv, pivout);  sweep16_step<4>(a, u, c, q, rowaddr, pv, pivout);  sweep16_step<5>(a, u, c, q, rowaddr, pv, pivout);
+    sweep16_step<6>(a, u, c, q, rowaddr, pv, pivout);  sweep16_step<7>(a, u, c, q, rowaddr, pv, pivout);  sweep16_step<8>(a, u, c, q, rowaddr, pv, pivout);
+    sweep16_step<9>(a, u, c, q, rowaddr, pv, pivout);  sweep16_step<10>(a, u, c, q, rowaddr, pv, pivout); sweep16_step<11>(a, u, c, q, rowaddr, pv, pivout);
+    sweep16_step<12>(a, u, c, q, rowaddr, pv, pivout); sweep16_step<13>(a, u, c, q, rowaddr, pv, pivout); sweep16_step<14>(a, u, c, q, rowaddr, pv, pivout);
+    sweep16_step<15>(a, u, c, q, rowaddr, pv, pivout);
     pv.fold();
 }
 
@@ -215,6 +216,92 @@ __device__ __forceinline__ void blk_sweep(double* W, int ld, int nb_used, int w,
         }
         if constexpr (NW > 1) __syncthreads();
     }
+}
+
+// ---- 256 x 256: the blocked sweep with the matrix in REGISTERS (1024 threads = 16 waves) ----------------------------------------------
+// A 256 x 256 fp64 matrix is 512 KiB: no LDS image (blk_sweep's form), but exactly the register file of one CU's worth of waves at 8 VGPRs
+// per 16 x 16 block.  Only the 136 upper blocks are kept, dealt round-robin (block p = I 16 - I (I - 1) / 2 + J - I to wave p % 16: 8 or 9
+// each, C/D layout).  Step K of the sweep:
+//   (a) the owner of (K, K) sweeps it in-wave (S = -inv(W_KK)) and leaves inv(W_KK) in LDS; the owners of the panel blocks -- (K, J) for
+//       J > K, (I, K) for I < K, i.e. the transposes of W_KI -- leave the OLD row panel T_J = W_KJ in an LDS strip (16 x 256, ld 258)
+//   (b) the panel owners form R_J = inv(W_KK) T_J (one 16 x 16 x 16 product each) into a second strip; (K, J) keeps R_J
+//   (c) every other block: W_IJ -= T_I' R_J (four fp64 MFMAs, both operands read from the strips); (I, K) takes R_I' back from the strip
+// -- three workgroup barriers per step, no global traffic between load and store, no product formed twice (blk_sweep's waves each form
+// the whole row panel themselves).  Replaces the Schur-complement inverse of rounds 1-2 (two register-tiled 128 x 128 Gauss-Jordans with a
+// barrier per pivot + four VALU GEMMs through global scratch: 0.38 ms alone, 0.46 beside a pass).
+// Kg: the SPD matrix (row-major, ld 256, identity-padded beyond its order); Out: its inverse, both triangles; pivs[256]: the pivots in
+// order (their logs sum to log det; a non-positive one = not positive definite).  lds: INV256_LDS_DOUBLES doubles.
+constexpr int INV256_LD = 258;
+constexpr int INV256_LDS_DOUBLES = 2 * 16 * INV256_LD + 16 * 18;
+// nb: 16 x 16 blocks actually present (the order rounded up; rows and columns beyond 16 nb are identity padding and are neither swept nor stored)
+__device__ __forceinline__ void inv256_blk(const double* __restrict__ Kg, double* __restrict__ Out, double* lds, double* pivs, int nb = 16) {
+    constexpr int LD = INV256_LD, NBLK = 136, NOWN = 9;
+    double* Tst = lds;
+    double* Rst = lds + 16 * LD;
+    double* Sb = lds + 2 * 16 * LD;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int bi[NOWN], bj[NOWN];
+    f64x4 blk[NOWN];
+#pragma unroll
+    for (int t = 0; t < NOWN; ++t) {
+        const int p = w + 16 * t;
+        int I = 0, start = 0;
+        while (I < 15 && p >= start + (16 - I)) { start += 16 - I; ++I; }    // (wave-uniform)
+        const bool have = p < NBLK && I + (p - start) < nb;       // (bi <= bj < nb)
+        bi[t] = have ? I : -1;
+        bj[t] = have ? I + (p - start) : -1;
+        blk[t] = f64x4{0.0, 0.0, 0.0, 0.0};
+        if (have) blk[t] = blk_ld_rows(Kg, 256, bi[t], bj[t], lane);
+    }
+    for (int K = 0; K < nb; ++K) {
+#pragma unroll
+        for (int t = 0; t < NOWN; ++t) {
+            if (bi[t] < 0) continue;
+            if (bi[t] == K && bj[t] == K) {
+                PivAcc pv;
+                sweep16(blk[t], lane, pv, pivs + 16 * K);                    // blk = -inv(W_KK): the block's final value
+                blk_st_rows(Sb, 18, 0, 0, lane, -blk[t]);
+            } else if (bi[t] == K) {
+                blk_st_rows(Tst, LD, 0, bj[t], lane, blk[t]);                // T_J = W_KJ
+            } else if (bj[t] == K) {
+                blk_st_cols(Tst, LD, 0, bi[t], lane, blk[t]);                // T_I = W_KI = (block (I, K))'
+            }
+        }
+        __syncthreads();
+        const f64x4 Sn = blk_ld_rows(Sb, 18, 0, 0, lane);                    // inv(W_KK), symmetric: its own A operand
+#pragma unroll
+        for (int t = 0; t < NOWN; ++t) {
+            if (bi[t] < 0 || (bi[t] == K) == (bj[t] == K)) continue;         // panel blocks only (exactly one index = K)
+            const int J = bi[t] == K ? bj[t] : bi[t];
+            const f64x4 b = blk_ld_rows(Tst, LD, 0, J, lane);
+            const f64x4 R = blk_mma(Sn, b, f64x4{0.0, 0.0, 0.0, 0.0});
+            blk_st_rows(Rst, LD, 0, J, lane, R);
+            if (bi[t] == K) blk[t] = R;                                      // (K, J) := R_J
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NOWN; ++t) {
+            if (bi[t] < 0) continue;
+            if (bi[t] != K && bj[t] != K) {
+                const f64x4 T = -blk_ld_rows(Tst, LD, 0, bi[t], lane);       // A operand chunks of W_IK = (T_I)'
+                const f64x4 Rj = blk_ld_rows(Rst, LD, 0, bj[t], lane);
+                blk[t] = blk_mma(T, Rj, blk[t]);
+            } else if (bj[t] == K && bi[t] != K) {
+                blk[t] = blk_ld_cols(Rst, LD, 0, bi[t], lane);               // (I, K) := R_I'
+            }
+        }
+        __syncthreads();
+    }
+    // the upper blocks hold -inv(W): both triangles out
+#pragma unroll
+    for (int t = 0; t < NOWN; ++t) {
+        if (bi[t] < 0) continue;
+        const f64x4 v = -blk[t];
+        blk_st_rows(Out, 256, bi[t], bj[t], lane, v);
+        if (bi[t] != bj[t]) blk_st_cols(Out, 256, bj[t], bi[t], lane, v);
+    }
+    __syncthreads();
 }
 
 }  // namespace vbmf

@@ -225,126 +225,11 @@ __device__ __forceinline__ void gj_tiled_n(double (&w)[NB][R][R], int n, double*
     }
 }
 
-// ---- 129 <= H <= 256: blocked inverse -----------------------------------------------------------
-// A 256 x 256 fp64 matrix is 512 KB -- the whole register file of a CU -- so the register-tiled sweep
-// above cannot hold it (its 8 x 8 tiles at 1024 threads spill: measured 2.4 ms).  Split K = [A B; B' D] into
-// 128-blocks and use the Schur complement, every piece a 128 x 128 problem that fits:
-//     Ai = inv(A);  W = Ai B;  S = D - B'W;  Si = inv(S);  X12 = -W Si;  X11 = Ai - X12 W';  X22 = Si
-// det K = det A det S, so the pivots of the two sweeps are K's log-determinant.  The two inverses run on the
-// register-tiled sweep (4 x 4 tiles, 1024 threads), the four products on a plain LDS-panelled fp64 GEMM
-// (thread (ty, tx) owns C[4ty..4ty+3][4tx..4tx+3]).  1024 threads; matrices in global memory (L2-resident).
-constexpr int GEMM_LD = 130;   // panel row stride in doubles: 16-byte aligned, rows 4 banks apart
-
-// c += P' Q' over k = 0..127 with P'(i,k) = TP ? P[k*ldp + i] : P[i*ldp + k],  Q'(k,j) = TQ ? Q[j*ldq + k] : Q[k*ldq + j]
-template <bool TP, bool TQ>
-__device__ __forceinline__ void gemm128_acc(double (&c)[4][4], const double* __restrict__ P, int ldp,
-                                            const double* __restrict__ Q, int ldq, double* panel) {
-    double* Ps = panel;
-    double* Qs = panel + 16 * GEMM_LD;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int k0 = 0; k0 < 128; k0 += 16) {
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int e = threadIdx.x + 1024 * r;
-            if (TP) { const int kk = e >> 7, i = e & 127; Ps[kk * GEMM_LD + i] = P[(long long)(k0 + kk) * ldp + i]; }
-            else    { const int i = e >> 4, kk = e & 15;  Ps[kk * GEMM_LD + i] = P[(long long)i * ldp + k0 + kk]; }
-            if (TQ) { const int j = e >> 4, kk = e & 15;  Qs[kk * GEMM_LD + j] = Q[(long long)j * ldq + k0 + kk]; }
-            else    { const int kk = e >> 7, j = e & 127; Qs[kk * GEMM_LD + j] = Q[(long long)(k0 + kk) * ldq + j]; }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-            const double2 a0 = *reinterpret_cast<const double2*>(Ps + kk * GEMM_LD + 4 * ty);
-            const double2 a1 = *reinterpret_cast<const double2*>(Ps + kk * GEMM_LD + 4 * ty + 2);
-            const double2 b0 = *reinterpret_cast<const double2*>(Qs + kk * GEMM_LD + 4 * tx);
-            const double2 b1 = *reinterpret_cast<const double2*>(Qs + kk * GEMM_LD + 4 * tx + 2);
-            const double a[4] = {a0.x, a0.y, a1.x, a1.y}, b[4] = {b0.x, b0.y, b1.x, b1.y};
-#pragma unroll
-            for (int x = 0; x < 4; ++x)
-#pragma unroll
-                for (int y = 0; y < 4; ++y) c[x][y] += a[x] * b[y];
-        }
-    }
-}
-
-// Kg: the SPD matrix, 256 x 256, row stride ld, identity-padded beyond H.  Out: its inverse (same shape).
-// Wm, Sm: 128 x 128 scratch (row stride 128).  lds: 2*16*GEMM_LD + 512 doubles.  pivs: 256 doubles (LDS).
-// Needs 1024 threads; every thread of the block must call it.
-__device__ __forceinline__ void inv256_schur(const double* __restrict__ Kg, double* __restrict__ Out, int ld,
-                                             double* __restrict__ Wm, double* __restrict__ Sm, double* lds,
-                                             double* pivs) {
-    double* panel = lds;
-    double* strip = lds + 2 * 16 * GEMM_LD;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    double w[4][4], c[4][4];
-    // 1. Ai = inv(A) -> Out[0:128, 0:128]
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) w[a][b] = Kg[(long long)(ty + 32 * a) * ld + tx + 32 * b];
-    gj_tiled<4, 32>(w, 128, strip, pivs);
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) Out[(long long)(ty + 32 * a) * ld + tx + 32 * b] = w[a][b];
-    // 2. W = Ai B
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int y = 0; y < 4; ++y) c[x][y] = 0.0;
-    gemm128_acc<false, false>(c, Out, ld, Kg + 128, ld, panel);
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int y = 0; y < 4; ++y) Wm[(4 * ty + x) * 128 + 4 * tx + y] = c[x][y];
-    // 3. S = D - B'W
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int y = 0; y < 4; ++y) c[x][y] = 0.0;
-    gemm128_acc<true, false>(c, Kg + 128, ld, Wm, 128, panel);
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int y = 0; y < 4; ++y)
-            Sm[(4 * ty + x) * 128 + 4 * tx + y] = Kg[(long long)(128 + 4 * ty + x) * ld + 128 + 4 * tx + y] - c[x][y];
-    __syncthreads();
-    // 4. Si = inv(S) -> Out[128:, 128:]
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) w[a][b] = Sm[(ty + 32 * a) * 128 + tx + 32 * b];
-    gj_tiled<4, 32>(w, 128, strip, pivs + 128);
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) Out[(long long)(128 + ty + 32 * a) * ld + 128 + tx + 32 * b] = w[a][b];
-    // 5. X12 = -W Si (and its transpose)
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int y = 0; y < 4; ++y) c[x][y] = 0.0;
-    gemm128_acc<false, false>(c, Wm, 128, Out + (long long)128 * ld + 128, ld, panel);
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int y = 0; y < 4; ++y) {
-            Out[(long long)(4 * ty + x) * ld + 128 + 4 * tx + y] = -c[x][y];
-            Out[(long long)(128 + 4 * tx + y) * ld + 4 * ty + x] = -c[x][y];
-        }
-    // 6. X11 = Ai - X12 W'
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int y = 0; y < 4; ++y) c[x][y] = 0.0;
-    gemm128_acc<false, true>(c, Out + 128, ld, Wm, 128, panel);
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int y = 0; y < 4; ++y) Out[(long long)(4 * ty + x) * ld + 4 * tx + y] -= c[x][y];
-    __syncthreads();
-}
+// ---- 129 <= H <= 256: the blocked sweep with the matrix in registers (inv256_blk, blk_inverse.hpp) ----------------------------------
+// A 256 x 256 fp64 matrix is 512 KB -- the whole register file of a CU -- so the LDS-image sweep of the smaller ranks cannot hold it.  Rounds
+// 1-2 split K = [A B; B' D] and took the Schur complement (two register-tiled 128 x 128 Gauss-Jordans with a barrier per pivot + four VALU
+// GEMMs through global scratch: 0.38 ms alone, 0.46-0.85 beside a pass); late in round 3 the 136 upper 16 x 16 blocks live in the registers
+// of the 16 waves and the sweep's row panel travels through LDS: 0.14 ms alone, 0.22-0.28 beside a pass, 3e-15 from a long-double reference.
 
 // relaxed agent-scope read of the loop's stop flag (bypasses this CU's L1: the flag may have been
 // raised a moment ago by ctrl_end in this very workgroup or by another one)
@@ -414,7 +299,7 @@ __device__ __forceinline__ void ctrl_cov_dev(double* __restrict__ st, StateLayou
     const double sigma2 = scal[S_SIGMA2];
     double* pivs;
     if constexpr (R == 8 && T == 32) {
-        // 129 <= H <= 256 (Hp = 256): blocked inverse through global scratch (inv256_schur)
+        // 129 <= H <= 256 (Hp = 256): the blocked sweep with the matrix in registers (inv256_blk, blk_inverse.hpp)
         double* Kg = st + lay.W0();
         double* Ki = st + lay.W1();
         for (int t = threadIdx.x; t < 256 * 256; t += 1024) {
@@ -427,8 +312,8 @@ __device__ __forceinline__ void ctrl_cov_dev(double* __restrict__ st, StateLayou
             Kg[t] = v;
         }
         __syncthreads();
-        pivs = lds + 2 * 16 * GEMM_LD + 512;
-        inv256_schur(Kg, Ki, 256, st + lay.W2(), st + lay.W2() + 128 * 128, lds, pivs);
+        pivs = lds + INV256_LDS_DOUBLES;
+        inv256_blk(Kg, Ki, lds, pivs, (H + 15) >> 4);
         for (int t = threadIdx.x; t < 256 * 256; t += 1024) {
             const int i = t >> 8, j = t & 255;
             const double v = (i < H && j < H) ? Ki[t] : 0.0;

@@ -379,13 +379,12 @@ __global__ __launch_bounds__(NW * 64) void sparse_update_a_full_wave_kernel(cons
     }
 }
 
-// 128 < H <= 256 (Hp = 256): a 256 x 256 fp64 block is the whole register file of a CU, so the column's block goes through the
-// blocked Schur inverse of the control chain (inv256_schur, ctrl_kernels.hpp: two 128 x 128 register-tiled inverses + four
-// LDS-panelled fp64 GEMMs) with the matrices in a per-workgroup GLOBAL workspace ws[b] = [K | inv(K) | W | S] (1.25 MiB, L2).
-// One 1024-thread workgroup per column and round; the running sum of the blocks lives in part[b] (read-modify-write: the
-// 64 values per thread would not fit beside the inverse's tiles).  ~0.4 ms per column: a correctness path for small M (the MIL
-// callers gate full_cov by M H <= 3200; the reference's own route inverts the dense MH x MH matrix).
-constexpr long long FULL256_WS = 2 * 256 * 256 + 2 * 128 * 128;           // doubles per workgroup
+// 128 < H <= 256 (Hp = 256): a 256 x 256 fp64 block is the whole register file of a CU: the column's block is inverted by the control
+// chain's register-resident blocked sweep (inv256_blk, blk_inverse.hpp) from / into a per-workgroup GLOBAL workspace ws[b] = [K | inv(K)]
+// (1 MiB, L2).  One 1024-thread workgroup per column and round; the running sum of the blocks lives in part[b] (read-modify-write: the
+// 64 values per thread would not fit beside the inverse's blocks).  ~0.15-0.2 ms per column (0.4 with the Schur-complement inverse of rounds
+// 1-2): a correctness path for small M (the MIL callers gate full_cov by M H <= 3200; the reference's own route inverts the dense MH x MH matrix).
+constexpr long long FULL256_WS = 2 * 256 * 256;                           // doubles per workgroup: the matrix and its inverse
 __global__ __launch_bounds__(1024) void sparse_update_a_full256_kernel(const float* __restrict__ P, long long ldP,
                                                                        const float* __restrict__ CA32,
                                                                        const double* __restrict__ st, StateLayout lay,
@@ -399,9 +398,7 @@ __global__ __launch_bounds__(1024) void sparse_update_a_full256_kernel(const flo
     constexpr int Hp = 256;
     double* Kg = ws + (long long)blockIdx.x * FULL256_WS;
     double* Ki = Kg + Hp * Hp;
-    double* Wm = Ki + Hp * Hp;
-    double* Sm = Wm + 128 * 128;
-    double* pivs = lds_f256 + 2 * 16 * GEMM_LD + 512;
+    double* pivs = lds_f256 + INV256_LDS_DOUBLES;
     double* pv = pivs + 256;
     double* mypart = part + (long long)blockIdx.x * Hp * Hp;
     const double sig = st[lay.scal() + S_SIGMA2];
@@ -421,7 +418,7 @@ __global__ __launch_bounds__(1024) void sparse_update_a_full256_kernel(const flo
         }
         if (threadIdx.x < Hp) pv[threadIdx.x] = threadIdx.x < H ? (double)P[(long long)threadIdx.x * ldP + m] : 0.0;
         __syncthreads();
-        inv256_schur(Kg, Ki, Hp, Wm, Sm, lds_f256, pivs);
+        inv256_blk(Kg, Ki, lds_f256, pivs, (H + 15) >> 4);
         __syncthreads();
         if (threadIdx.x < H) { const double pq = pivs[threadIdx.x]; if (!(pq > 0.0) || !isfinite(pq)) bad = 1; }
         {   // vec(A')[m,:] = msc * inv(K_m) (B'Y)[:, m]: four threads per row, 64 columns each
@@ -653,7 +650,7 @@ __global__ __launch_bounds__(T * T) void sparse_cov_b_kernel(double* __restrict_
     const double* cb = st + lay.cb();
     double* pivs;
     if constexpr (R == 8 && T == 32) {
-        // 129 <= H <= 256 (Hp = 256): blocked inverse through global scratch (inv256_schur, ctrl_kernels.hpp)
+        // 129 <= H <= 256 (Hp = 256): the blocked sweep with the matrix in registers (inv256_blk, blk_inverse.hpp)
         double* Kg = st + lay.W0();
         double* Ki = st + lay.W1();
         for (int t = threadIdx.x; t < 256 * 256; t += 1024) {
@@ -666,8 +663,8 @@ __global__ __launch_bounds__(T * T) void sparse_cov_b_kernel(double* __restrict_
             Kg[t] = v;
         }
         __syncthreads();
-        pivs = lds_scb + 2 * 16 * GEMM_LD + 512;
-        inv256_schur(Kg, Ki, 256, st + lay.W2(), st + lay.W2() + 128 * 128, lds_scb, pivs);
+        pivs = lds_scb + INV256_LDS_DOUBLES;
+        inv256_blk(Kg, Ki, lds_scb, pivs, (H + 15) >> 4);
         for (int t = threadIdx.x; t < 256 * 256; t += 1024) {
             const int i = t >> 8, j = t & 255;
             const double v = (i < H && j < H) ? Ki[t] : 0.0;

@@ -753,7 +753,7 @@ static bool side_overlap(const vbmf_ctx* c) { return c->in_run && c->NH == 8; }
 
 template <int R, int T>
 static void launch_cov_t(vbmf_ctx* c, int which, hipStream_t s) {
-    const size_t lds = (R == 8 && T == 32) ? (size_t)(2 * 16 * GEMM_LD + 512 + 256) * sizeof(double) : spd_inverse_lds_bytes(R);
+    const size_t lds = (R == 8 && T == 32) ? (size_t)(INV256_LDS_DOUBLES + 256) * sizeof(double) : spd_inverse_lds_bytes(R);
     const double N = which == 0 ? (double)c->Lg : (double)c->M;
     hipLaunchKernelGGL((ctrl_cov_kernel<R, T>), dim3(1), dim3(T * T), lds, s, c->st, c->lay, (int)c->H, which, N,
                        which == 0 ? c->SA32 : c->SB32, c->ints);
@@ -1327,6 +1327,10 @@ int vbmf_create(vbmf_ctx** out, int64_t L, int64_t M, int64_t H, const vbmf_opts
         // 64 < H <= 128: the blocked inverse keeps the 128 x 130 fp64 image in LDS (133 KB)
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ctrl_cov_kernel<8, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)sparse_cov_b_kernel<8, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
+        // 128 < H <= 256: the register-resident blocked sweep's two panel strips (70 KB: above the 64 KB a launch may ask for unannounced)
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ctrl_cov_kernel<8, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)sparse_cov_b_kernel<8, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)sparse_update_a_full256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, c->lds_limit);
         if (e == hipSuccess && c->NH == 4) {
             using Cfg = StreamCfg<4>;
             DISPATCH_MODE(c->mode, {
@@ -2086,7 +2090,7 @@ static double digamma_host(double x) {
 
 template <int R, int T>
 static void launch_scov_t(vbmf_ctx* c) {
-    const size_t lds = (R == 8 && T == 32) ? (size_t)(2 * 16 * GEMM_LD + 512 + 256) * sizeof(double) : spd_inverse_lds_bytes(R);
+    const size_t lds = (R == 8 && T == 32) ? (size_t)(INV256_LDS_DOUBLES + 256) * sizeof(double) : spd_inverse_lds_bytes(R);
     hipLaunchKernelGGL((sparse_cov_b_kernel<R, T>), dim3(1), dim3(T * T), lds, ctrl_stream(c), c->st, c->lay, (int)c->H, c->SB32, c->ints, c->diagvar ? 1 : 0);
 }
 static int launch_sparse_cov_b(vbmf_ctx* c) {
@@ -2201,7 +2205,7 @@ static int do_sparse_update_A(vbmf_ctx* c, bool reuse_P = false) {
         else if (H <= 64) nparts = launch_full_a_wave<4, 4>(c, Gw);
         else if (H <= 128) launch_full_a_t<8, 16, 1>(c, Gw);   // 64 < H <= 128: one column per round and workgroup
         else                                               // 128 < H <= 256: blocked Schur inverse through a global workspace
-            hipLaunchKernelGGL(sparse_update_a_full256_kernel, dim3(c->fblocks), dim3(1024), (size_t)(2 * 16 * GEMM_LD + 512 + 256 + 256) * sizeof(double),
+            hipLaunchKernelGGL(sparse_update_a_full256_kernel, dim3(c->fblocks), dim3(1024), (size_t)(INV256_LDS_DOUBLES + 256 + 256) * sizeof(double),
                                c->stream, c->Pred, (long long)c->d1.XT * 32, c->CA32, c->st, c->lay, c->A32, c->dS32,
                                c->has_mask ? c->mask : nullptr, (int)(c->H - c->H1), (long long)c->M, H, (double)c->Lg, c->fpart, c->ints, Gw, c->fws);
         hipLaunchKernelGGL(full_sa_fold_kernel, dim3(cdiv(c->Hp * c->Hp, 256)), dim3(256), 0, c->stream, c->fpart, nparts, c->Hp, c->st, c->lay, stop);
