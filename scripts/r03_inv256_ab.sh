@@ -1,4 +1,9 @@
 #!/bin/bash
+# inv256_blk against the Schur-complement inverse it replaced: the previous commit's library as an A/B variant, alternating on one box.
+# Build the variant first (in the build container):
+#   mkdir -p /tmp/prevsrc variants && git archive <commit before inv256_blk> vbmatrixfactorization.jl_amd/csrc include | tar -x -C /tmp/prevsrc
+#   (cd /tmp/prevsrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared vbmatrixfactorization.jl_amd/csrc/vbmf_hip.hip -o $REPO/variants/libvbmf_prev.so -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib)
+# then: gpurun -- bash scripts/r03_inv256_ab.sh      (the capi picks the variant up through VBMF_HIP_LIB)
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R
 out=$R/gpurun_out/r03_inv256_ab; mkdir -p $out
 for r in 1 2; do
